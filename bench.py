@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- skinned vertices/sec of the deformation hot path on MI355X, with the HBM roofline of
+the dominant kernel and the reference CPU path timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]/[3], SURVEY.md section 8d "config 3/4"): a crowd of 1024 instances PER GPU
+of the synthetic 50 000-vertex / 300-bone / 200-morph model, per-instance bone palettes resident in
+HBM, one shared morph state, outputs = Poser::pose_image (f32 positions + normals, 24 B / vertex)
+resident in HBM.  One STEP = one mmdx_deform_batched() call = the whole hot path over the crowd
+(group-morph flatten -> shared morph pass -> skinning + write-out).  Instances shard across ranks
+with no data-path collective ("scaling": "weak"); torch.distributed (gloo) is used only for the
+start/stop barriers and the max-over-ranks reduction of the elapsed time.
+
+The config-2 (single 50k model, latency) and config-5 (256k verts, fp16 positions) figures ride
+along under "other_workloads"; they are not the headline value.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s measured copy
+
+
+def algorithmic_bytes_config3(nv, nb, nm, ne, ni, n1, n2, n4):
+    """SURVEY.md section 8d, minimal encodings.  Returns (deform kernel bytes, whole step bytes)."""
+    static = nv * (12 + 12 + 1) + n1 * 2 + n2 * 8 + n4 * 24
+    deform = static + nv * 12 + ni * (nv * 24 + nb * 48)          # + shared morphed positions read
+    morph = ne * 16 + nv * 12 + nm * 4                            # table + morphed write + weights
+    return deform, deform + morph
+
+
+def shard(total_instances: int, world: int, rank: int):
+    """Instance range of `rank`: [rank*NI/G, (rank+1)*NI/G)."""
+    return (rank * total_instances) // world, ((rank + 1) * total_instances) // world
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--instances-per-gpu", type=int, default=1024)
+    ap.add_argument("--layout", choices=["soa", "vertex32"], default="soa")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    # The product library first (it binds the HIP runtime at load), torch only for rendezvous.
+    from simple_mmd_renderer_amd import _capi as api
+    from simple_mmd_renderer_amd import build, synth
+    from simple_mmd_renderer_amd.engine import (DeformModel, DeviceBuffer, device_count, device_name,
+                                                device_select, device_synchronize)
+    build.build()
+    api.lib()
+    ndev = device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no HIP device visible -- this engine has no CPU path to fall back to")
+    device_select(local_rank % ndev)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- workload ------------------------------------------------------------------------------
+    model = synth.make_config("config3_crowd")
+    ni = args.instances_per_gpu
+    lo, hi = shard(ni * world, world, rank)
+    frames = (np.arange(lo, hi) * 3) % 1801                 # phase-shifted animation per instance
+    pals = synth.make_palettes(model, frames, seed=7 + rank)
+    rates = synth.morph_weights(model.nm, 30)[0]
+    layout = api.OUT_SOA if args.layout == "soa" else api.OUT_VERTEX32
+    pos_scale = 1.0 if layout == api.OUT_SOA else 0.1
+
+    dm = DeformModel(model)
+    info = dm.info
+    d_pal = DeviceBuffer.from_numpy(pals)
+    d_w = DeviceBuffer.from_numpy(rates)
+    sa, sb = dm.out_sizes(layout, ni)
+    d_a = DeviceBuffer(sa)
+    d_b = DeviceBuffer(sb) if sb else None
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+
+    def step():
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout, flags,
+                              pos_scale)
+
+    for _ in range(args.warmup):
+        step()
+    device_synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    dm.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = dm.timer_stop()                 # HIP events on the launch stream; also drains it
+    device_synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations, HIP events around each launch (outside the timed region) ---------
+    dm.profile_enable(True)
+    skin_ms, morph_ms = [], []
+    for _ in range(max(10, min(args.steps, 50))):
+        step()
+        s, m_ = dm.profile_last()
+        skin_ms.append(s)
+        morph_ms.append(m_)
+    dm.profile_enable(False)
+    skin_avg = float(np.mean(skin_ms))
+    morph_avg = float(np.mean(morph_ms))
+
+    total_vertices = float(ni) * world * model.nv * args.steps
+    value = total_vertices / elapsed
+    deform_bytes, step_bytes = algorithmic_bytes_config3(model.nv, model.nb, model.nm, info.n_entries, ni,
+                                                         info.n_bdef1, info.n_bdef2, info.n_bdef4)
+    if layout == api.OUT_VERTEX32:
+        deform_bytes += ni * model.nv * 8 + model.nv * 8        # 32 B out + uv in
+        step_bytes += ni * model.nv * 8 + model.nv * 8
+    achieved = deform_bytes / (skin_avg * 1e-3) / 1e9
+
+    result = {
+        "metric": "skinned vertices/sec (instance-sharded crowd); achieved HBM GB/s vs roofline",
+        "value": value, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config3: 1024-instance crowd per GPU of the 50k-vert/300-bone/200-morph "
+                               "model, shared morph state, per-instance palettes in HBM",
+                   "instances_per_gpu": ni, "vertices": model.nv, "bones": model.nb, "morphs": model.nm,
+                   "morph_entries": int(info.n_entries), "out_layout": args.layout,
+                   "sharding": f"instances/{world} ranks, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "deform_kernel (skinning + write-out)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": deform_bytes, "avg_kernel_ms": skin_avg,
+                     "step_algorithmic_bytes": step_bytes, "morph_pass_ms": morph_avg,
+                     "step_event_ms": ev_ms / args.steps},
+    }
+
+    if rank == 0:
+        result["device"] = device_name(local_rank % ndev)
+        # practical ceilings on this box (SURVEY.md section 8d asks for them next to the spec peak)
+        nb_ceiling = 1 << 30
+        src, dst = DeviceBuffer(nb_ceiling), DeviceBuffer(nb_ceiling)
+        src.memset(1)
+        import ctypes as C
+        ms = C.c_float(0)
+        api.check(api.lib().mmdx_bench_copy(dst.ptr, src.ptr, nb_ceiling, 10, C.byref(ms)))
+        result["roofline"]["measured_copy_GBs"] = 2 * nb_ceiling / (ms.value * 1e-3) / 1e9
+        api.check(api.lib().mmdx_bench_fill(dst.ptr, nb_ceiling, 10, C.byref(ms)))
+        result["roofline"]["measured_fill_GBs"] = nb_ceiling / (ms.value * 1e-3) / 1e9
+        src.free()
+        dst.free()
+
+    # ---- CPU baseline: rank 0, N=1 only ------------------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.pyoracle import Oracle, Reference, reference_available   # checker, CPU leg only
+        reps = 8
+        if reference_available():
+            ref = Reference(model, normalize=True)
+            secs = sum(ref.time_crowd(rates, pals) for _ in range(reps))
+            ref.close()
+            kind = "reference"
+            what = "libmmd Poser (g++ -O2): 1 morph pass + 1024 x {palette inject, Deform()}"
+        else:
+            orc = Oracle()
+            secs = sum(orc.time_crowd(model, rates, pals) for _ in range(reps))
+            kind = "port"
+            what = "C restatement (gcc -O2): 1 morph pass + 1024 x skinning pass"
+        result["cpu_baseline"] = {"value": reps * ni * model.nv / secs, "unit": "vertices/s", "cores": 1,
+                                  "kind": kind,
+                                  "sample": f"{reps} x the full config-3 crowd step ({what}), "
+                                            f"{secs:.1f} s of CPU work, single thread as the reference runs"}
+
+    # ---- other BASELINE configs (rank 0, N=1): reported, not the headline --------------------------
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["other_workloads"] = extras(api, synth, DeformModel, DeviceBuffer, dm, model)
+
+    d_pal.free(); d_w.free(); d_a.free()
+    if d_b:
+        d_b.free()
+    dm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def time_calls(dm, fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    dm.sync()
+    dm.timer_start()
+    for _ in range(iters):
+        fn()
+    return dm.timer_stop() / iters
+
+
+def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
+    out = {}
+    flags_dev = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+
+    # config 2: single 50k model, 200 active morphs -- per-launch latency and 64 frames per launch
+    nfr = 64
+    frames = np.arange(nfr)
+    pals = synth.make_palettes(model3, frames)
+    rates = synth.morph_weights(model3.nm, frames)
+    d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
+    sa, sb = dm3.out_sizes(api.OUT_SOA, nfr)
+    d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+    ms1 = time_calls(dm3, lambda: dm3.deform_batched_raw(1, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
+                                                         api.OUT_SOA, flags_dev), 200)
+    ms64 = time_calls(dm3, lambda: dm3.deform_batched_raw(nfr, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
+                                                          api.OUT_SOA, flags_dev), 50)
+    i = dm3.info
+    static = model3.nv * 25 + i.n_bdef1 * 2 + i.n_bdef2 * 8 + i.n_bdef4 * 24
+    table = i.n_entries * 16
+    b1 = static + table + model3.nv * 24 + model3.nb * 48 + model3.nm * 4
+    b64 = static + table + nfr * (model3.nv * 24 + model3.nb * 48 + model3.nm * 4)
+    out["config2_single_frame"] = {"ms_per_call": ms1, "vertices_per_s": model3.nv / (ms1 * 1e-3),
+                                   "algorithmic_GBs": b1 / (ms1 * 1e-3) / 1e9,
+                                   "note": "one 50k-vert frame per launch: launch-latency bound"}
+    out["config2_64_frames_per_launch"] = {"ms_per_call": ms64,
+                                           "vertices_per_s": nfr * model3.nv / (ms64 * 1e-3),
+                                           "algorithmic_GBs": b64 / (ms64 * 1e-3) / 1e9,
+                                           "frac_of_8TBs": b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    for b in (d_pal, d_w, d_a, d_b):
+        b.free()
+
+    # config 5: 262 144 verts, 512 bones, 1024 morphs x 4096 entries, fp16 positions
+    m5 = synth.make_config("config5_256k")
+    dm5 = DeformModel(m5, f16_positions=True)
+    pals = synth.make_palettes(m5, frames)
+    rates = synth.morph_weights(m5.nm, frames)
+    d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
+    sa, sb = dm5.out_sizes(api.OUT_SOA_POS16, nfr)
+    d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+    ms1 = time_calls(dm5, lambda: dm5.deform_batched_raw(1, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
+                                                         api.OUT_SOA_POS16, flags_dev), 100)
+    ms64 = time_calls(dm5, lambda: dm5.deform_batched_raw(nfr, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
+                                                          api.OUT_SOA_POS16, flags_dev), 20)
+    i = dm5.info
+    static = m5.nv * (6 + 12 + 1) + i.n_bdef1 * 2 + i.n_bdef2 * 8 + i.n_bdef4 * 24
+    table = i.n_entries * 10
+    b1 = static + table + m5.nv * 18 + m5.nb * 48 + m5.nm * 4
+    b64 = static + table + nfr * (m5.nv * 18 + m5.nb * 48 + m5.nm * 4)
+    out["config5_single_frame_fp16"] = {"ms_per_call": ms1, "vertices_per_s": m5.nv / (ms1 * 1e-3),
+                                        "algorithmic_GBs": b1 / (ms1 * 1e-3) / 1e9}
+    out["config5_64_frames_per_launch_fp16"] = {"ms_per_call": ms64,
+                                                "vertices_per_s": nfr * m5.nv / (ms64 * 1e-3),
+                                                "algorithmic_GBs": b64 / (ms64 * 1e-3) / 1e9,
+                                                "frac_of_8TBs": b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    for b in (d_pal, d_w, d_a, d_b):
+        b.free()
+    dm5.close()
+    return out
+
+
+if __name__ == "__main__":
+    main()

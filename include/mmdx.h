@@ -1,0 +1,216 @@
+/* mmdx.h -- C ABI of the MI355X-native per-frame deformation engine for MMD/PMX models.
+ *
+ * This is the drop-in boundary for ONE path of CU-Production/simple_mmd_renderer: the per-vertex
+ * morph-target blend + BDEF1/2/4/SDEF linear-blend skinning that the vendored libmmd evaluates on
+ * one CPU thread every frame, plus the viewer's repack into its 32-byte vertex stream:
+ *
+ *     reference (L/ = 3rd_party/libmmd/include/mmd/)              replaced by
+ *     ----------------------------------------------------------  -------------------------------
+ *     mmd::Model vertex/skin/morph stores  L/model/model.inl:21-104,  mmdx_model_create()
+ *         :334-517, :719-726; Model::Normalize L/model/model_impl.inl:406-452
+ *     Poser::SetMorphPose + morph part of PrePhysicsPosing +        morph_weights argument of
+ *         UpdateMorphTransform  L/motion/poser_impl.inl:328-346,       mmdx_deform*()
+ *         :362-365, :384-386, :478-480
+ *     Poser::BoneImage::skinning_matrix_ (the palette, read through  palette argument of
+ *         PhysicsReactor::GetPoserBoneImage L/motion/physics.inl:32-40) mmdx_deform*()
+ *     Poser::Deform -> Poser::pose_image  L/motion/poser_impl.inl:396-461,  mmdx_deform*(), layout
+ *         L/motion/poser.inl:17-20                                       MMDX_OUT_SOA
+ *     UpdateDeformedVertices (struct Vertex, x0.1 scale, uv copy)    mmdx_deform*(), layout
+ *         main.cpp:50-54, :821-863                                       MMDX_OUT_VERTEX32
+ *     call site frame() main.cpp:1821 + :1824                        one mmdx_deform() call
+ *
+ * Everything else of the viewer (bone solve, VMD evaluation, Bullet, sokol draw loop) is untouched:
+ * the host keeps producing morph rates and the bone palette and hands them over per frame.
+ *
+ * Conventions
+ *   - Matrices: row-vector, row-major float[16], y = x * M, translation in elements 12..14
+ *     (L/util/math.inl:383-395; identical to an OpenGL column-major float[16]).
+ *   - No exceptions cross this boundary: every call returns an mmdx_status; the text of the last
+ *     error on the calling thread is available from mmdx_last_error_string().
+ *   - All indices are validated in mmdx_model_create(); mmdx_deform*() can only fail on argument
+ *     errors or HIP runtime errors.
+ *   - A model handle owns its device allocations and one HIP stream; calls on one handle are not
+ *     re-entrant; different handles (and devices) may be driven from different host threads.
+ *   - Results are bit-identical to the reference's CPU path (the kernels are compiled with
+ *     -ffp-contract=off and keep the reference's operation order); see DESIGN.md.
+ */
+#ifndef MMDX_H_INCLUDED
+#define MMDX_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MMDX_API __attribute__((visibility("default")))
+#else
+#define MMDX_API
+#endif
+
+#define MMDX_ABI_VERSION 1u
+
+typedef int32_t mmdx_status;
+enum {
+    MMDX_OK = 0,
+    MMDX_ERR_INVALID_ARGUMENT = 1, /* NULL / size / flag problems                                  */
+    MMDX_ERR_BAD_INDEX = 2,        /* a bone, vertex or morph index in the model is out of range   */
+    MMDX_ERR_NO_DEVICE = 3,        /* no usable HIP device (the product has no CPU fallback)       */
+    MMDX_ERR_HIP = 4,              /* a HIP runtime call failed; see mmdx_last_error_string()      */
+    MMDX_ERR_OUT_OF_MEMORY = 5,
+    MMDX_ERR_UNSUPPORTED = 6       /* e.g. morph group cycle, > 65535 bones in one vertex tile     */
+};
+
+/* Deform-type tags = PMX / libmmd values (L/model/model.inl:23-28).  Any other value is legal and
+ * takes the reference's `default:` branch, i.e. is evaluated as BDEF2 (poser_impl.inl:417-418).
+ * SDEF is evaluated as BDEF2 as well: the reference's spherical-deform code is commented out
+ * ("UNDONE", poser_impl.inl:438-458). */
+enum { MMDX_SKIN_BDEF1 = 0, MMDX_SKIN_BDEF2 = 1, MMDX_SKIN_BDEF4 = 2, MMDX_SKIN_SDEF = 3 };
+
+/* Morph-type tags (L/model/model.inl:488-498).  Only GROUP and VERTEX move vertices; BONE feeds the
+ * host's bone solve; UV / EXT_UV / MATERIAL are ignored by the reference path and by this engine. */
+enum { MMDX_MORPH_GROUP = 0, MMDX_MORPH_VERTEX = 1, MMDX_MORPH_BONE = 2, MMDX_MORPH_UV = 3,
+       MMDX_MORPH_MATERIAL = 8 };
+
+/* mmdx_model_desc.flags */
+enum {
+    MMDX_CREATE_NORMALIZE = 1u << 0, /* apply Model::Normalize retagging (needs bone_parent)        */
+    MMDX_CREATE_HOST_ONLY = 1u << 1, /* build + validate the plan only; touch no device (for tests
+                                        and tools on machines without a GPU; deform then fails)     */
+    MMDX_CREATE_F16_POSITIONS = 1u << 2 /* keep base positions and morph offsets as IEEE binary16 in
+                                        HBM (rounded to nearest even once, here); arithmetic stays
+                                        f32.  Bandwidth-stress configuration, not reference parity */
+};
+
+/* Flat model description.  All pointers are host pointers, borrowed for the duration of the call. */
+typedef struct mmdx_model_desc {
+    uint32_t struct_size; /* = sizeof(mmdx_model_desc)                                             */
+    uint32_t flags;       /* MMDX_CREATE_*                                                         */
+    uint32_t n_vertices, n_bones, n_morphs;
+    uint32_t reserved0;
+    const float *positions;    /* [NV][3]                                                          */
+    const float *normals;      /* [NV][3]                                                          */
+    const float *uvs;          /* [NV][2] or NULL (zeros)                                          */
+    const int32_t *skin_type;  /* [NV] MMDX_SKIN_* (raw PMX tag)                                    */
+    const int32_t *bone_ids;   /* [NV][4]  BDEF1: [0]; BDEF2/SDEF: [0],[1]; BDEF4: [0..3]          */
+    const float *bone_weights; /* [NV][4]  BDEF2/SDEF: [0] = weight of bone [0]; BDEF4: [0..3]     */
+    const float *sdef_params;  /* [NV][9] C,R0,R1 or NULL -- accepted, validated for size only      */
+    const int32_t *bone_parent; /* [NB] (-1 = none) or NULL; used only by MMDX_CREATE_NORMALIZE    */
+    const int32_t *morph_type;  /* [NM] MMDX_MORPH_*                                               */
+    const uint32_t *morph_offset; /* [NM+1] entry range of morph m = [off[m], off[m+1])            */
+    const uint32_t *morph_index;  /* [E] vertex index (VERTEX) / morph index (GROUP) / other       */
+    const float *morph_value;     /* [E][3] offset xyz (VERTEX) / {rate,-,-} (GROUP) / other       */
+} mmdx_model_desc;
+
+typedef struct mmdx_model_s *mmdx_model_t;
+
+/* Output layouts */
+enum {
+    MMDX_OUT_SOA = 0,      /* out_a = f32 pos[NI][NV][3], out_b = f32 nrm[NI][NV][3]
+                              (= Poser::pose_image.coordinates / .normals)                          */
+    MMDX_OUT_VERTEX32 = 1, /* out_a = struct{f32 pos[3]; f32 normal[3]; f32 uv[2];}[NI][NV]
+                              (= main.cpp:50-54); out_b unused                                     */
+    MMDX_OUT_SOA_POS16 = 2 /* out_a = f16 pos[NI][NV][3], out_b = f32 nrm[NI][NV][3]               */
+};
+
+/* mmdx_deform_args.flags */
+enum {
+    MMDX_PALETTE_ON_DEVICE = 1u << 0, /* palettes is a device pointer (else host, copied per call)  */
+    MMDX_WEIGHTS_ON_DEVICE = 1u << 1, /* morph_weights is a device pointer                          */
+    MMDX_OUT_ON_DEVICE = 1u << 2,     /* out_a/out_b are device pointers (else host; D2H + sync)   */
+    MMDX_WEIGHTS_SHARED = 1u << 3     /* one morph_weights[NM] for all instances (crowd with shared
+                                         facial state): the morph pass runs once per call          */
+};
+
+typedef struct mmdx_deform_args {
+    uint32_t struct_size;  /* = sizeof(mmdx_deform_args)                                           */
+    uint32_t flags;        /* MMDX_*_ON_DEVICE | MMDX_WEIGHTS_SHARED                               */
+    uint32_t n_instances;  /* NI >= 1                                                              */
+    uint32_t out_layout;   /* MMDX_OUT_*                                                           */
+    const float *morph_weights; /* [NI][NM], or [NM] with MMDX_WEIGHTS_SHARED; may be NULL if NM==0 */
+    const float *palettes;      /* [NI][NB][16]                                                    */
+    void *out_a;
+    void *out_b;
+    float pos_scale; /* positions are multiplied by this AFTER the transform, as a separate f32
+                        multiply (main.cpp:848-850 uses 0.1f); 1.0f = leave as pose_image          */
+    uint32_t reserved0;
+} mmdx_deform_args;
+
+typedef struct mmdx_model_info {
+    uint32_t struct_size;
+    uint32_t n_vertices, n_bones, n_morphs;
+    uint32_t n_slots;          /* vertex-morph applications in the reference's traversal order      */
+    uint32_t n_entries;        /* vertex-morph entries after group expansion (CSR length)           */
+    uint32_t n_tiles, tile_vertices;
+    uint32_t n_bdef1, n_bdef2, n_bdef4; /* after optional Normalize; SDEF/unknown count as bdef2   */
+    uint32_t max_tile_bones;
+    uint64_t device_bytes;     /* static streams resident in HBM                                   */
+    uint32_t device_ordinal;
+    uint32_t flags;
+} mmdx_model_info;
+
+/* ---- library / device ------------------------------------------------------------------------ */
+MMDX_API uint32_t mmdx_abi_version(void);
+MMDX_API const char *mmdx_last_error_string(void);
+MMDX_API mmdx_status mmdx_device_count(int32_t *count);
+MMDX_API mmdx_status mmdx_device_select(int32_t ordinal); /* device for subsequently created models */
+MMDX_API mmdx_status mmdx_device_name(int32_t ordinal, char *buf, size_t buf_size);
+
+/* ---- model ----------------------------------------------------------------------------------- */
+MMDX_API mmdx_status mmdx_model_create(const mmdx_model_desc *desc, mmdx_model_t *out_model);
+MMDX_API mmdx_status mmdx_model_destroy(mmdx_model_t model);
+MMDX_API mmdx_status mmdx_model_get_info(mmdx_model_t model, mmdx_model_info *info);
+/* Post-Normalize skin tags in ORIGINAL vertex order: type[NV] (0,1,2), ids[NV][4], weights[NV][4]. */
+MMDX_API mmdx_status mmdx_model_get_skin(mmdx_model_t model, int32_t *type, int32_t *ids,
+                                         float *weights);
+/* Host-side flattening of group morphs: slot_weights[n_slots] for one set of morph rates, exactly
+ * what the device consumes (a slot whose chain hits the reference's `rate < 1e-7` skip gets 0). */
+MMDX_API mmdx_status mmdx_model_slot_weights(mmdx_model_t model, const float *morph_weights,
+                                             float *slot_weights);
+/* Borrow an external HIP stream (hipStream_t) instead of the handle's own; NULL restores it. */
+MMDX_API mmdx_status mmdx_model_set_stream(mmdx_model_t model, void *hip_stream);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/* deform(model, morph_weights, bone_palette, out_verts): one instance, host pointers, synchronous.
+ * out_pos/out_nrm = f32[NV][3] each = Poser::pose_image after Poser::Deform(). */
+MMDX_API mmdx_status mmdx_deform(mmdx_model_t model, const float *morph_weights /*[NM]*/,
+                                 const float *palette /*[NB][16]*/, float *out_pos, float *out_nrm);
+/* Same, producing the viewer's interleaved 32-byte vertices (Deform + UpdateDeformedVertices). */
+MMDX_API mmdx_status mmdx_deform_vertex32(mmdx_model_t model, const float *morph_weights,
+                                          const float *palette, float pos_scale,
+                                          void *out_vertices /*[NV] x 32 B*/);
+/* General / crowd form.  Asynchronous on the handle's stream when every pointer is a device pointer;
+ * otherwise returns after the copies have completed. */
+MMDX_API mmdx_status mmdx_deform_batched(mmdx_model_t model, const mmdx_deform_args *args);
+MMDX_API mmdx_status mmdx_sync(mmdx_model_t model);
+
+/* ---- timing on the handle's stream (HIP events; for bench harnesses) ------------------------- */
+MMDX_API mmdx_status mmdx_timer_start(mmdx_model_t model);
+MMDX_API mmdx_status mmdx_timer_stop(mmdx_model_t model, float *elapsed_ms); /* syncs the stream  */
+/* Milliseconds spent in the skinning kernel(s) / morph kernel(s) of the LAST mmdx_deform_batched
+ * call, measured with HIP events around each launch when enabled (adds event overhead). */
+MMDX_API mmdx_status mmdx_profile_enable(mmdx_model_t model, int32_t enabled);
+MMDX_API mmdx_status mmdx_profile_last(mmdx_model_t model, float *skin_ms, float *morph_ms);
+
+/* ---- plain device-memory helpers (thin hipMalloc / hipMemcpy wrappers) ----------------------- */
+/* So that C, C++ and ctypes callers can keep palettes and outputs resident in HBM without linking
+ * the HIP runtime themselves. */
+MMDX_API mmdx_status mmdx_device_malloc(void **ptr, size_t bytes);
+MMDX_API mmdx_status mmdx_device_free(void *ptr);
+MMDX_API mmdx_status mmdx_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);
+MMDX_API mmdx_status mmdx_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
+MMDX_API mmdx_status mmdx_device_memset(void *dst_device, int value, size_t bytes);
+MMDX_API mmdx_status mmdx_device_synchronize(void);
+/* Device-to-device streaming copy / fill timed with HIP events: the practical HBM ceiling printed
+ * next to the roofline.  bytes_moved = 2*bytes for copy, bytes for fill. */
+MMDX_API mmdx_status mmdx_bench_copy(void *dst_device, const void *src_device, size_t bytes,
+                                     int32_t iterations, float *avg_ms);
+MMDX_API mmdx_status mmdx_bench_fill(void *dst_device, size_t bytes, int32_t iterations,
+                                     float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMDX_H_INCLUDED */

@@ -1,0 +1,229 @@
+"""ctypes front-ends for the two CHECKER libraries -- TEST INFRASTRUCTURE ONLY.
+
+  Oracle    -> oracle/libmmdx_oracle.so   (from-scratch C restatement, oracle/mmdx_oracle.c)
+  Reference -> oracle/_ref/libmmd_ref.so  (the real libmmd, oracle/ref_harness.cpp; build container
+                                           only -- the prebuilt .so travels to the GPU box)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The
+product (simple_mmd_renderer_amd/) never does; it fails loudly when its HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libmmdx_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libmmd_ref.so")
+
+
+def build(quiet: bool = True) -> None:
+    """Compile the restatement (and the reference harness when /root/reference is mounted)."""
+    subprocess.run(["make", "-C", _HERE] + (["-s"] if quiet else []), check=True)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Oracle:
+    """The C restatement.  All methods take/return numpy arrays; nothing is cached."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        self.lib = C.CDLL(ORACLE_SO)
+        self.lib.mmdx_oracle_time_crowd.restype = C.c_double
+
+    def normalize(self, model):
+        """Model::Normalize retagging; returns (type i32[NV], ids i64[NV,4], w f32[NV,4]) copies."""
+        t = _c(model.skin_type, np.int32).copy()
+        ids = _c(model.bone_ids, np.int64).copy()
+        w = _c(model.bone_weights, np.float32).copy()
+        par = _c(model.bone_parent, np.int64)
+        self.lib.mmdx_oracle_normalize(C.c_uint32(model.nv), _p(t, C.c_int32), _p(ids, C.c_int64),
+                                       _p(w, C.c_float), _p(par, C.c_int64))
+        return t, ids, w
+
+    def morph(self, model, rates):
+        vimg = np.zeros((model.nv, 3), np.float32)
+        rates = _c(rates, np.float32)
+        assert rates.shape == (model.nm,)
+        self.lib.mmdx_oracle_morph(
+            C.c_uint32(model.nv), C.c_uint32(model.nm), _p(_c(model.morph_type, np.int32), C.c_int32),
+            _p(_c(model.morph_off, np.uint32), C.c_uint32),
+            _p(_c(model.morph_index, np.uint32), C.c_uint32),
+            _p(_c(model.morph_value, np.float32), C.c_float), _p(rates, C.c_float),
+            _p(vimg, C.c_float))
+        return vimg
+
+    def skin(self, model, palette, vimg=None, skin=None, positions=None):
+        """Poser::Deform.  `skin` = (type, ids, w) as returned by normalize(), else the raw tags."""
+        t, ids, w = skin if skin is not None else (
+            _c(model.skin_type, np.int32), _c(model.bone_ids, np.int64),
+            _c(model.bone_weights, np.float32))
+        pos = _c(model.positions if positions is None else positions, np.float32)
+        nrm = _c(model.normals, np.float32)
+        pal = _c(palette, np.float32).reshape(-1, 16)
+        assert pal.shape[0] == model.nb
+        out_p = np.empty((model.nv, 3), np.float32)
+        out_n = np.empty((model.nv, 3), np.float32)
+        vi = _c(vimg, np.float32) if vimg is not None else None
+        self.lib.mmdx_oracle_skin(C.c_uint32(model.nv), _p(pos, C.c_float), _p(nrm, C.c_float),
+                                  _p(vi, C.c_float), _p(_c(t, np.int32), C.c_int32),
+                                  _p(_c(ids, np.int64), C.c_int64), _p(_c(w, np.float32), C.c_float),
+                                  _p(pal, C.c_float), _p(out_p, C.c_float), _p(out_n, C.c_float))
+        return out_p, out_n
+
+    def repack32(self, model, pos, nrm, pos_scale):
+        out = np.empty((model.nv, 8), np.float32)
+        self.lib.mmdx_oracle_repack32(C.c_uint32(model.nv), _p(_c(pos, np.float32), C.c_float),
+                                      _p(_c(nrm, np.float32), C.c_float),
+                                      _p(_c(model.uvs, np.float32), C.c_float),
+                                      C.c_float(pos_scale), _p(out, C.c_float))
+        return out
+
+    def deform(self, model, rates, palette, normalize=True):
+        """Whole path: (optional) Normalize -> morph pass -> Deform.  Returns (pos, nrm)."""
+        skin = self.normalize(model) if normalize else None
+        vimg = self.morph(model, rates)
+        return self.skin(model, palette, vimg, skin)
+
+    def time_crowd(self, model, rates, palettes, normalize=True):
+        """Seconds for one crowd step (shared morph pass + one skinning pass per palette)."""
+        t, ids, w = self.normalize(model) if normalize else (
+            _c(model.skin_type, np.int32), _c(model.bone_ids, np.int64),
+            _c(model.bone_weights, np.float32))
+        pal = _c(palettes, np.float32).reshape(-1, model.nb, 16)
+        vimg = np.zeros((model.nv, 3), np.float32)
+        op = np.empty((model.nv, 3), np.float32)
+        on = np.empty((model.nv, 3), np.float32)
+        return float(self.lib.mmdx_oracle_time_crowd(
+            C.c_uint32(model.nv), C.c_uint32(model.nb), C.c_uint32(model.nm),
+            _p(_c(model.positions, np.float32), C.c_float), _p(_c(model.normals, np.float32), C.c_float),
+            _p(t, C.c_int32), _p(ids, C.c_int64), _p(w, C.c_float),
+            _p(_c(model.morph_type, np.int32), C.c_int32), _p(_c(model.morph_off, np.uint32), C.c_uint32),
+            _p(_c(model.morph_index, np.uint32), C.c_uint32),
+            _p(_c(model.morph_value, np.float32), C.c_float), _p(_c(rates, np.float32), C.c_float),
+            C.c_uint32(pal.shape[0]), _p(pal, C.c_float), _p(vimg, C.c_float), _p(op, C.c_float),
+            _p(on, C.c_float)))
+
+
+def reference_available() -> bool:
+    return os.path.exists(REF_SO)
+
+
+class Reference:
+    """The real libmmd Poser driven through oracle/ref_harness.cpp."""
+
+    def __init__(self, model, normalize=True):
+        if not reference_available():
+            raise RuntimeError("oracle/_ref/libmmd_ref.so not built (needs /root/reference)")
+        lib = C.CDLL(REF_SO)
+        lib.mmdref_create.restype = C.c_void_p
+        lib.mmdref_time_frames.restype = C.c_double
+        lib.mmdref_time_crowd.restype = C.c_double
+        self.lib, self.model = lib, model
+        sdef = _c(model.sdef, np.float32) if model.sdef is not None else None
+        self._keep = [
+            _c(model.positions, np.float32), _c(model.normals, np.float32), _c(model.uvs, np.float32),
+            _c(model.skin_type, np.int32), _c(model.bone_ids, np.int64),
+            _c(model.bone_weights, np.float32), sdef, _c(model.bone_pos, np.float32),
+            _c(model.bone_parent, np.int64), _c(model.morph_type, np.int32),
+            _c(model.morph_off, np.uint32), _c(model.morph_index, np.uint32),
+            _c(model.morph_value, np.float32)]
+        k = self._keep
+        self.h = C.c_void_p(lib.mmdref_create(
+            C.c_uint32(model.nv), C.c_uint32(model.nb), C.c_uint32(model.nm),
+            _p(k[0], C.c_float), _p(k[1], C.c_float), _p(k[2], C.c_float), _p(k[3], C.c_int32),
+            _p(k[4], C.c_int64), _p(k[5], C.c_float), _p(k[6], C.c_float), _p(k[7], C.c_float),
+            _p(k[8], C.c_int64), _p(k[9], C.c_int32), _p(k[10], C.c_uint32), _p(k[11], C.c_uint32),
+            _p(k[12], C.c_float), C.c_int(1 if normalize else 0)))
+
+    def close(self):
+        if self.h:
+            self.lib.mmdref_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_skin(self):
+        nv = self.model.nv
+        t = np.empty(nv, np.int32)
+        ids = np.empty((nv, 4), np.int64)
+        w = np.empty((nv, 4), np.float32)
+        self.lib.mmdref_get_skin(self.h, _p(t, C.c_int32), _p(ids, C.c_int64), _p(w, C.c_float))
+        return t, ids, w
+
+    def reset_posing(self):
+        self.lib.mmdref_reset_posing(self.h)
+
+    def set_bone_pose(self, i, t, q):
+        t = _c(t, np.float32)
+        q = _c(q, np.float32)
+        self.lib.mmdref_set_bone_pose(self.h, C.c_uint32(i), _p(t, C.c_float), _p(q, C.c_float))
+
+    def set_morphs(self, rates):
+        for i, r in enumerate(np.asarray(rates, np.float32)):
+            self.lib.mmdref_set_morph(self.h, C.c_uint32(i), C.c_float(float(r)))
+
+    def pose(self):
+        self.lib.mmdref_pose(self.h)
+
+    def get_palette(self):
+        out = np.empty((self.model.nb, 16), np.float32)
+        self.lib.mmdref_get_palette(self.h, _p(out, C.c_float))
+        return out
+
+    def set_palette(self, pal):
+        pal = _c(pal, np.float32).reshape(self.model.nb, 16)
+        self.lib.mmdref_set_palette(self.h, _p(pal, C.c_float))
+
+    def deform(self):
+        self.lib.mmdref_deform(self.h)
+        pos = np.empty((self.model.nv, 3), np.float32)
+        nrm = np.empty((self.model.nv, 3), np.float32)
+        self.lib.mmdref_get_pose_image(self.h, _p(pos, C.c_float), _p(nrm, C.c_float))
+        return pos, nrm
+
+    def repack32(self, pos_scale=0.1):
+        out = np.empty((self.model.nv, 8), np.float32)
+        self.lib.mmdref_repack32(self.h, C.c_float(pos_scale), _p(out, C.c_float))
+        return out
+
+    def run(self, rates, palette=None):
+        """ResetPosing -> SetMorphPose x NM -> Pre/PostPhysicsPosing -> [inject palette] -> Deform.
+        Returns (pos, nrm, palette_used)."""
+        self.reset_posing()
+        self.set_morphs(rates)
+        self.pose()
+        if palette is not None:
+            self.set_palette(palette)
+        pal = self.get_palette()
+        pos, nrm = self.deform()
+        return pos, nrm, pal
+
+    def time_frames(self, rates, palettes=None):
+        rates = _c(rates, np.float32).reshape(-1, self.model.nm)
+        pal = _c(palettes, np.float32) if palettes is not None else None
+        scratch = np.empty((self.model.nv, 8), np.float32)
+        return float(self.lib.mmdref_time_frames(self.h, C.c_uint32(rates.shape[0]),
+                                                 _p(rates, C.c_float), _p(pal, C.c_float),
+                                                 _p(scratch, C.c_float)))
+
+    def time_crowd(self, rates, palettes):
+        pal = _c(palettes, np.float32).reshape(-1, self.model.nb, 16)
+        return float(self.lib.mmdref_time_crowd(self.h, C.c_uint32(pal.shape[0]),
+                                                _p(_c(rates, np.float32), C.c_float),
+                                                _p(pal, C.c_float)))

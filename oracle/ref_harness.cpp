@@ -1,0 +1,306 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin C driver around the REAL reference implementation: the vendored header-only libmmd that
+// CU-Production/simple_mmd_renderer evaluates on the CPU every frame.  libmmd is #included BY PATH
+// from /root/reference (no reference source is copied into this repo); the result is built into
+// oracle/_ref/libmmd_ref.so by oracle/Makefile.  It is used to
+//   (1) validate the from-scratch C restatement (oracle/mmdx_oracle.c),
+//   (2) generate the golden vectors committed under tests/golden/ (oracle/gen_golden.py),
+//   (3) optionally serve as bench.py's cpu_baseline (kind "reference") when the prebuilt .so is present.
+//
+// What is driven (reference file:line):
+//   * Model builder API            L/model/model.inl:204-281, :669-689 (NewBone/NewVertex/NewMorph ...)
+//   * Model::Normalize             L/model/model_impl.inl:406-452
+//   * Poser ctor / posing          L/motion/poser_impl.inl:16-140, :362-394
+//   * Poser::Deform                L/motion/poser_impl.inl:396-461
+//   * palette tap / inject         L/motion/physics.inl:32-40 (protected GetPoserBoneImage, exactly
+//                                  how include/mmd-bullet writes skinning_matrix_)
+//   * 32-byte repack               main.cpp:50-54, :838-859 (app code; needs sokol, cannot be compiled
+//                                  here, so the 10 lines of arithmetic are re-expressed below)
+// (L/ = 3rd_party/libmmd/include/mmd/)
+
+#include <mmd/mmd.hxx>
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// The reference's only plugin interface; deriving from it is the legal way to reach
+// Poser::bone_images_[i].skinning_matrix_.
+class PaletteTap : public mmd::PhysicsReactor {
+public:
+    void AddPoser(mmd::Poser &) override {}
+    void RemovePoser(mmd::Poser &) override {}
+    void Reset() override {}
+    void React(float) override {}
+    void SetGravityStrength(float) override {}
+    void SetGravityDirection(const mmd::Vector3f &) override {}
+    float GetGravityStrength() const override { return 0.f; }
+    mmd::Vector3f GetGravityDirection() const override { return mmd::Vector3f(); }
+    void SetFloor(bool) override {}
+    bool IsHasFloor() const override { return false; }
+
+    static float *Matrix(mmd::Poser &poser, size_t i) {
+        return GetPoserBoneImage(poser, i).skinning_matrix_.v;
+    }
+};
+
+struct Ref {
+    mmd::Model model;
+    mmd::Poser *poser = nullptr;
+    ~Ref() { delete poser; }
+};
+
+inline mmd::Vector3f V3(const float *p) {
+    mmd::Vector3f v;
+    v.v[0] = p[0]; v.v[1] = p[1]; v.v[2] = p[2];
+    return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Flat model description (same meaning as include/mmdx.h's mmdx_model_desc):
+//   skin_type[NV]          raw SkinningType value (0 BDEF1, 1 BDEF2, 2 BDEF4, 3 SDEF, other = "unknown")
+//   bone_ids[NV][4]        int64, -1 allowed for "none" (becomes size_t(-1))
+//   bone_weights[NV][4]    BDEF2/SDEF use [0]
+//   sdef[NV][9] or NULL    C, R0, R1
+//   bone_pos[NB][3], bone_parent[NB] (int64, -1 = root)
+//   morph_type[NM], morph_off[NM+1], morph_index[E], morph_value[E][3]
+//       vertex morph: index = vertex, value = offset
+//       group  morph: index = morph,  value[0] = rate
+//       bone   morph: index = bone,   value = translation (rotation = identity)
+//       uv/ext-uv/material: index = vertex/material, value ignored beyond being stored where it fits
+void *mmdref_create(uint32_t nv, uint32_t nb, uint32_t nm,
+                    const float *positions, const float *normals, const float *uvs,
+                    const int32_t *skin_type, const int64_t *bone_ids, const float *bone_weights,
+                    const float *sdef,
+                    const float *bone_pos, const int64_t *bone_parent,
+                    const int32_t *morph_type, const uint32_t *morph_off,
+                    const uint32_t *morph_index, const float *morph_value,
+                    int normalize) {
+    Ref *r = new Ref;
+    mmd::Model &m = r->model;
+    m.SetExtraUVNumber(0);
+    for (uint32_t b = 0; b < nb; ++b) {
+        mmd::Model::Bone &bone = m.NewBone();
+        bone.SetName(L"b" + std::to_wstring(b));
+        bone.SetPosition(V3(bone_pos + 3 * b));
+        bone.SetParentIndex(bone_parent[b] < 0 ? size_t(-1) : size_t(bone_parent[b]));
+        bone.SetTransformLevel(0);
+        bone.SetHasIK(false);
+        bone.SetAppendRotate(false);
+        bone.SetAppendTranslate(false);
+        bone.SetPostPhysics(false);
+    }
+    for (uint32_t i = 0; i < nv; ++i) {
+        mmd::Model::Vertex<mmd::ref> v = m.NewVertex();
+        v.SetCoordinate(V3(positions + 3 * i));
+        v.SetNormal(V3(normals + 3 * i));
+        if (uvs) {
+            mmd::Vector2f uv;
+            uv.v[0] = uvs[2 * i]; uv.v[1] = uvs[2 * i + 1];
+            v.SetUVCoordinate(uv);
+        }
+        mmd::Model::SkinningOperator &op = v.GetSkinningOperator();
+        std::memset(&op, 0, sizeof(op));
+        const int64_t *id = bone_ids + 4 * i;
+        const float *w = bone_weights + 4 * i;
+        op.SetSkinningType(mmd::Model::SkinningOperator::SkinningType(skin_type[i]));
+        switch (skin_type[i]) {
+        case 0:
+            op.GetBDEF1().SetBoneID(size_t(id[0]));
+            break;
+        case 2:
+            for (int k = 0; k < 4; ++k) {
+                op.GetBDEF4().SetBoneID(k, size_t(id[k]));
+                op.GetBDEF4().SetBoneWeight(k, w[k]);
+            }
+            break;
+        case 3:
+            op.GetSDEF().SetBoneID(0, size_t(id[0]));
+            op.GetSDEF().SetBoneID(1, size_t(id[1]));
+            op.GetSDEF().SetBoneWeight(w[0]);
+            if (sdef) {
+                op.GetSDEF().SetC(V3(sdef + 9 * i));
+                op.GetSDEF().SetR0(V3(sdef + 9 * i + 3));
+                op.GetSDEF().SetR1(V3(sdef + 9 * i + 6));
+            }
+            break;
+        default:  // BDEF2 and every unknown tag
+            op.GetBDEF2().SetBoneID(0, size_t(id[0]));
+            op.GetBDEF2().SetBoneID(1, size_t(id[1]));
+            op.GetBDEF2().SetBoneWeight(w[0]);
+            break;
+        }
+    }
+    for (uint32_t k = 0; k < nm; ++k) {
+        mmd::Model::Morph &morph = m.NewMorph();
+        morph.SetName(L"m" + std::to_wstring(k));
+        morph.SetType(mmd::Model::Morph::MorphType(morph_type[k]));
+        for (uint32_t e = morph_off[k]; e < morph_off[k + 1]; ++e) {
+            mmd::Model::Morph::MorphData &d = morph.NewMorphData();
+            std::memset(&d, 0, sizeof(d));
+            switch (morph_type[k]) {
+            case 0:
+                d.GetGroupMorph().SetMorphIndex(morph_index[e]);
+                d.GetGroupMorph().SetMorphRate(morph_value[3 * e]);
+                break;
+            case 1:
+                d.GetVertexMorph().SetVertexIndex(morph_index[e]);
+                d.GetVertexMorph().SetOffset(V3(morph_value + 3 * e));
+                break;
+            case 2: {
+                d.GetBoneMorph().SetBoneIndex(morph_index[e]);
+                d.GetBoneMorph().SetTranslation(V3(morph_value + 3 * e));
+                mmd::Vector4f q;
+                q.q = mmd::Quaternionf::Identity();
+                d.GetBoneMorph().SetRotation(q);
+                break;
+            }
+            case 8:
+                d.GetMaterialMorph().SetMaterialIndex(morph_index[e]);
+                break;
+            default: {  // UV / extra UV
+                d.GetUVMorph().SetVertexIndex(morph_index[e]);
+                mmd::Vector4f o;
+                o.v[0] = morph_value[3 * e]; o.v[1] = morph_value[3 * e + 1];
+                o.v[2] = morph_value[3 * e + 2]; o.v[3] = 0.f;
+                d.GetUVMorph().SetOffset(o);
+                break;
+            }
+            }
+        }
+    }
+    if (normalize) m.Normalize();
+    r->poser = new mmd::Poser(m);
+    return r;
+}
+
+void mmdref_destroy(void *h) { delete static_cast<Ref *>(h); }
+
+// Skin tags after the optional Normalize() -- lets tests check the load-time retagging.
+void mmdref_get_skin(void *h, int32_t *type_out, int64_t *ids_out, float *w_out) {
+    Ref *r = static_cast<Ref *>(h);
+    size_t nv = r->model.GetVertexNum();
+    for (size_t i = 0; i < nv; ++i) {
+        mmd::Model::Vertex<mmd::ref> vertex = r->model.GetVertex(i);
+        const mmd::Model::SkinningOperator &op = vertex.GetSkinningOperator();
+        int t = int(op.GetSkinningType());
+        type_out[i] = t;
+        for (int k = 0; k < 4; ++k) { ids_out[4 * i + k] = -1; w_out[4 * i + k] = 0.f; }
+        if (t == 0) {
+            ids_out[4 * i] = int64_t(op.GetBDEF1().GetBoneID());
+        } else if (t == 2) {
+            for (int k = 0; k < 4; ++k) {
+                ids_out[4 * i + k] = int64_t(op.GetBDEF4().GetBoneID(k));
+                w_out[4 * i + k] = op.GetBDEF4().GetBoneWeight(k);
+            }
+        } else {
+            ids_out[4 * i] = int64_t(op.GetBDEF2().GetBoneID(0));
+            ids_out[4 * i + 1] = int64_t(op.GetBDEF2().GetBoneID(1));
+            w_out[4 * i] = op.GetBDEF2().GetBoneWeight();
+        }
+    }
+}
+
+void mmdref_reset_posing(void *h) { static_cast<Ref *>(h)->poser->ResetPosing(); }
+
+void mmdref_set_bone_pose(void *h, uint32_t i, const float *t, const float *q) {
+    mmd::Vector4f rot;
+    rot.v[0] = q[0]; rot.v[1] = q[1]; rot.v[2] = q[2]; rot.v[3] = q[3];
+    static_cast<Ref *>(h)->poser->SetBonePose(size_t(i), mmd::Motion::BonePose(V3(t), rot));
+}
+
+void mmdref_set_morph(void *h, uint32_t i, float w) {
+    static_cast<Ref *>(h)->poser->SetMorphPose(size_t(i), mmd::Motion::MorphPose(w));
+}
+
+// PrePhysicsPosing (morph accumulate + bone solve + palette) then PostPhysicsPosing.
+void mmdref_pose(void *h) {
+    Ref *r = static_cast<Ref *>(h);
+    r->poser->PrePhysicsPosing();
+    r->poser->PostPhysicsPosing();
+}
+
+void mmdref_get_palette(void *h, float *out) {
+    Ref *r = static_cast<Ref *>(h);
+    size_t nb = r->model.GetBoneNum();
+    for (size_t b = 0; b < nb; ++b) std::memcpy(out + 16 * b, PaletteTap::Matrix(*r->poser, b), 64);
+}
+
+void mmdref_set_palette(void *h, const float *in) {
+    Ref *r = static_cast<Ref *>(h);
+    size_t nb = r->model.GetBoneNum();
+    for (size_t b = 0; b < nb; ++b) std::memcpy(PaletteTap::Matrix(*r->poser, b), in + 16 * b, 64);
+}
+
+void mmdref_deform(void *h) { static_cast<Ref *>(h)->poser->Deform(); }
+
+void mmdref_get_pose_image(void *h, float *pos, float *nrm) {
+    Ref *r = static_cast<Ref *>(h);
+    size_t nv = r->model.GetVertexNum();
+    std::memcpy(pos, r->poser->pose_image.coordinates.data(), nv * 12);
+    std::memcpy(nrm, r->poser->pose_image.normals.data(), nv * 12);
+}
+
+// main.cpp:838-859 arithmetic: pos * 0.1f per component, normal and uv copied.
+void mmdref_repack32(void *h, float pos_scale, float *out) {
+    Ref *r = static_cast<Ref *>(h);
+    size_t nv = r->model.GetVertexNum();
+    for (size_t i = 0; i < nv; ++i) {
+        mmd::Model::Vertex<mmd::ref> vertex = r->model.GetVertex(i);
+        mmd::Vector2f uv = vertex.GetUVCoordinate();
+        const mmd::Vector3f &p = r->poser->pose_image.coordinates[i];
+        const mmd::Vector3f &n = r->poser->pose_image.normals[i];
+        float *o = out + 8 * i;
+        o[0] = p.p.x * pos_scale; o[1] = p.p.y * pos_scale; o[2] = p.p.z * pos_scale;
+        o[3] = n.p.x; o[4] = n.p.y; o[5] = n.p.z;
+        o[6] = uv.v[0]; o[7] = uv.v[1];
+    }
+}
+
+// ---- CPU-baseline timing helpers (seconds, single thread = how the reference runs) ----------
+
+// Whole reference frame as frame() sequences it (main.cpp:1786-1825), minus motion seek/physics:
+// ResetPosing -> SetMorphPose x NM -> PrePhysicsPosing -> PostPhysicsPosing -> [palette inject]
+// -> Deform -> 32-B repack.  `palettes` = frames x NB x 16 floats or NULL (keep solved palette).
+double mmdref_time_frames(void *h, uint32_t frames, const float *rates /*[frames][NM]*/,
+                          const float *palettes, float *scratch32 /*[NV][8]*/) {
+    Ref *r = static_cast<Ref *>(h);
+    size_t nm = r->model.GetMorphNum(), nb = r->model.GetBoneNum();
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t f = 0; f < frames; ++f) {
+        r->poser->ResetPosing();
+        for (size_t k = 0; k < nm; ++k)
+            r->poser->SetMorphPose(k, mmd::Motion::MorphPose(rates[f * nm + k]));
+        r->poser->PrePhysicsPosing();
+        r->poser->PostPhysicsPosing();
+        if (palettes) mmdref_set_palette(h, palettes + size_t(f) * nb * 16);
+        r->poser->Deform();
+        mmdref_repack32(h, 0.1f, scratch32);
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Crowd step: one shared morph pass, then per instance {inject palette; Deform()}.
+double mmdref_time_crowd(void *h, uint32_t instances, const float *rates /*[NM]*/,
+                         const float *palettes /*[instances][NB][16]*/) {
+    Ref *r = static_cast<Ref *>(h);
+    size_t nm = r->model.GetMorphNum(), nb = r->model.GetBoneNum();
+    auto t0 = std::chrono::steady_clock::now();
+    for (size_t k = 0; k < nm; ++k) r->poser->SetMorphPose(k, mmd::Motion::MorphPose(rates[k]));
+    r->poser->PrePhysicsPosing();
+    r->poser->PostPhysicsPosing();
+    for (uint32_t i = 0; i < instances; ++i) {
+        mmdref_set_palette(h, palettes + size_t(i) * nb * 16);
+        r->poser->Deform();
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+"""Build the in-tree HIP library (libmmdx.so) for gfx950 with hipcc.
+
+    python -m simple_mmd_renderer_amd.build [--force]
+
+One explicit hipcc command, no build system: the product is three translation units.  The .so is
+git-ignored but travels to the GPU box with the working tree.  -ffp-contract=off is part of the
+contract (bit-exact parity with the reference's CPU arithmetic), not a debug flag.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmmdx.so")
+SOURCES = ["api.cpp", "kernels.hip", "plan.cpp"]
+HEADERS = ["kernels.hpp", "plan.hpp", os.path.join("..", "..", "include", "mmdx.h")]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def flags() -> list[str]:
+    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+            "-fvisibility=hidden", "-Wall", "-Wextra", "-Wno-unused-parameter"]
+
+
+def up_to_date() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and up_to_date():
+        return LIB
+    cmd = [hipcc()] + flags() + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed")
+    if verbose and r.stderr:
+        sys.stderr.write(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

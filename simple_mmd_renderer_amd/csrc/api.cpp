@@ -1,0 +1,556 @@
+// api.cpp -- the C ABI of include/mmdx.h over the HIP runtime.  Host side of the drop-in boundary:
+// validates and compiles the model once (plan.cpp), keeps the static streams resident in HBM, and
+// turns one mmdx_deform*() call into at most three launches on the handle's stream:
+//     [flatten group morphs -> slot weights] -> [shared morph pass] -> deform (skin + write-out).
+// There is NO CPU fallback: without a usable HIP device every compute entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mmdx.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace mmdx;
+
+namespace {
+
+thread_local std::string g_err;
+int g_device = 0;
+std::once_flag g_prepare_once[16];
+hipError_t g_prepare_status[16];
+
+mmdx_status fail(mmdx_status st, const std::string &msg) {
+    g_err = msg;
+    return st;
+}
+
+mmdx_status hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+    // leave no sticky error behind for the next call
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? MMDX_ERR_OUT_OF_MEMORY
+                                    : (e == hipErrorNoDevice ? MMDX_ERR_NO_DEVICE : MMDX_ERR_HIP);
+}
+
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);      \
+    } while (0)
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&ptr, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; bytes = 0;
+    }
+};
+
+template <typename T>
+hipError_t upload(DevBuf &b, const std::vector<T> &v, uint64_t &total) {
+    const size_t n = std::max<size_t>(v.size() * sizeof(T), 16);  // never a null stream pointer
+    hipError_t e = b.ensure(n);
+    if (e != hipSuccess) return e;
+    total += n;
+    if (!v.empty()) return hipMemcpy(b.ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return hipSuccess;
+}
+
+}  // namespace
+
+struct mmdx_model_s {
+    Plan plan;
+    int device = -1;  // -1: host-only
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_m0 = nullptr,
+               ev_m1 = nullptr;
+    bool profile = false, prof_valid = false, prof_morph = false;
+    uint64_t device_bytes = 0;
+    // static streams
+    DevBuf tiles, spos, snrm, suv, perm, skin1, skin2_ids, skin2_w, skin4_ids, skin4_w, bone_list,
+        row_ptr, entries, slot_top, chain_off, chain_rate;
+    // per-call scratch (grown on demand, reused)
+    DevBuf pal, rates, wslot, morphed, out_a, out_b;
+};
+
+namespace {
+
+int env_int(const char *name, int dflt) {
+    const char *s = std::getenv(name);
+    return s && *s ? std::atoi(s) : dflt;
+}
+
+mmdx_status upload_model(mmdx_model_s *m) {
+    Plan &p = m->plan;
+    uint64_t &t = m->device_bytes;
+    HIP_TRY(upload(m->tiles, p.tiles, t));
+    if (p.f16) HIP_TRY(upload(m->spos, p.spos16, t)); else HIP_TRY(upload(m->spos, p.spos, t));
+    HIP_TRY(upload(m->snrm, p.snrm, t));
+    HIP_TRY(upload(m->suv, p.suv, t));
+    HIP_TRY(upload(m->perm, p.perm, t));
+    HIP_TRY(upload(m->skin1, p.skin1, t));
+    HIP_TRY(upload(m->skin2_ids, p.skin2_ids, t));
+    HIP_TRY(upload(m->skin2_w, p.skin2_w, t));
+    HIP_TRY(upload(m->skin4_ids, p.skin4_ids, t));
+    HIP_TRY(upload(m->skin4_w, p.skin4_w, t));
+    HIP_TRY(upload(m->bone_list, p.bone_list, t));
+    HIP_TRY(upload(m->row_ptr, p.row_ptr, t));
+    if (p.f16) HIP_TRY(upload(m->entries, p.entries16, t)); else HIP_TRY(upload(m->entries, p.entries, t));
+    HIP_TRY(upload(m->slot_top, p.slot_top, t));
+    HIP_TRY(upload(m->chain_off, p.chain_off, t));
+    HIP_TRY(upload(m->chain_rate, p.chain_rate, t));
+    if (p.ns) {
+        HIP_TRY(m->morphed.ensure(size_t(p.nv) * 12));
+        t += size_t(p.nv) * 12;
+    }
+    return MMDX_OK;
+}
+
+void free_model(mmdx_model_s *m) {
+    if (m->device >= 0) {
+        (void)hipSetDevice(m->device);
+        for (DevBuf *b : {&m->tiles, &m->spos, &m->snrm, &m->suv, &m->perm, &m->skin1, &m->skin2_ids,
+                          &m->skin2_w, &m->skin4_ids, &m->skin4_w, &m->bone_list, &m->row_ptr,
+                          &m->entries, &m->slot_top, &m->chain_off, &m->chain_rate, &m->pal, &m->rates,
+                          &m->wslot, &m->morphed, &m->out_a, &m->out_b})
+            b->release();
+        for (hipEvent_t ev : {m->ev_t0, m->ev_t1, m->ev_s0, m->ev_s1, m->ev_m0, m->ev_m1})
+            if (ev) (void)hipEventDestroy(ev);
+        if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    }
+    delete m;
+}
+
+size_t out_bytes_a(uint32_t layout, uint64_t nvi) {
+    return size_t(layout == MMDX_OUT_SOA ? nvi * 12 : (layout == MMDX_OUT_VERTEX32 ? nvi * 32 : nvi * 6));
+}
+size_t out_bytes_b(uint32_t layout, uint64_t nvi) {
+    return size_t(layout == MMDX_OUT_VERTEX32 ? 0 : nvi * 12);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mmdx_abi_version(void) { return MMDX_ABI_VERSION; }
+
+const char *mmdx_last_error_string(void) { return g_err.c_str(); }
+
+mmdx_status mmdx_device_count(int32_t *count) {
+    if (!count) return fail(MMDX_ERR_INVALID_ARGUMENT, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return hip_fail(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_device_select(int32_t ordinal) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (ordinal < 0 || ordinal >= n || ordinal >= 16)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(ordinal));
+    g_device = ordinal;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_device_name(int32_t ordinal, char *buf, size_t buf_size) {
+    if (!buf || !buf_size) return fail(MMDX_ERR_INVALID_ARGUMENT, "buf is NULL");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
+    std::snprintf(buf, buf_size, "%s %s cus=%d lds=%zu l2=%d memclk=%d buswidth=%d", prop.name,
+                  prop.gcnArchName, prop.multiProcessorCount, prop.sharedMemPerBlock,
+                  prop.l2CacheSize, prop.memoryClockRate, prop.memoryBusWidth);
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_model_create(const mmdx_model_desc *desc, mmdx_model_t *out_model) {
+    if (!desc || !out_model) return fail(MMDX_ERR_INVALID_ARGUMENT, "desc / out_model is NULL");
+    *out_model = nullptr;
+    mmdx_model_s *m = new (std::nothrow) mmdx_model_s;
+    if (!m) return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    std::string err;
+    mmdx_status st;
+    try {
+        st = build_plan(*desc, m->plan, err);
+    } catch (const std::bad_alloc &) {
+        delete m;
+        return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed while compiling the model");
+    }
+    if (st != MMDX_OK) {
+        delete m;
+        return fail(st, err);
+    }
+    if (desc->flags & MMDX_CREATE_HOST_ONLY) {
+        *out_model = m;
+        return MMDX_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        delete m;
+        return fail(MMDX_ERR_NO_DEVICE,
+                    "no HIP device available (this engine has no CPU fallback; use "
+                    "MMDX_CREATE_HOST_ONLY to validate a model without a GPU)");
+    }
+    m->device = g_device;
+    auto bail = [&](mmdx_status s) { free_model(m); return s; };
+    if ((e = hipSetDevice(m->device)) != hipSuccess) return bail(hip_fail(e, "hipSetDevice"));
+    std::call_once(g_prepare_once[m->device], [&] { g_prepare_status[m->device] = prepare_kernels(); });
+    if (g_prepare_status[m->device] != hipSuccess)
+        return bail(hip_fail(g_prepare_status[m->device], "hipFuncSetAttribute(dynamic LDS)"));
+    if ((e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(hip_fail(e, "hipStreamCreate"));
+    m->stream = m->own_stream;
+    for (hipEvent_t *ev : {&m->ev_t0, &m->ev_t1, &m->ev_s0, &m->ev_s1, &m->ev_m0, &m->ev_m1})
+        if ((e = hipEventCreate(ev)) != hipSuccess) return bail(hip_fail(e, "hipEventCreate"));
+    st = upload_model(m);
+    if (st != MMDX_OK) return bail(st);
+    *out_model = m;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_model_destroy(mmdx_model_t model) {
+    if (!model) return MMDX_OK;
+    if (model->device >= 0) {
+        (void)hipSetDevice(model->device);
+        (void)hipStreamSynchronize(model->stream);
+    }
+    free_model(model);
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_model_get_info(mmdx_model_t m, mmdx_model_info *info) {
+    if (!m || !info) return fail(MMDX_ERR_INVALID_ARGUMENT, "model / info is NULL");
+    if (info->struct_size != sizeof(mmdx_model_info))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_model_info.struct_size mismatch");
+    const Plan &p = m->plan;
+    info->n_vertices = p.nv; info->n_bones = p.nb; info->n_morphs = p.nm;
+    info->n_slots = p.ns; info->n_entries = p.ne;
+    info->n_tiles = p.ntiles; info->tile_vertices = kTileVerts;
+    info->n_bdef1 = p.n1; info->n_bdef2 = p.n2; info->n_bdef4 = p.n4;
+    info->max_tile_bones = p.max_tile_bones;
+    info->device_bytes = m->device_bytes;
+    info->device_ordinal = m->device < 0 ? 0xffffffffu : uint32_t(m->device);
+    info->flags = p.flags;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_model_get_skin(mmdx_model_t m, int32_t *type, int32_t *ids, float *weights) {
+    if (!m || !type || !ids || !weights) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    const Plan &p = m->plan;
+    for (uint32_t i = 0; i < p.nv; ++i)
+        type[i] = p.cls[i] == 0 ? MMDX_SKIN_BDEF1 : (p.cls[i] == 1 ? MMDX_SKIN_BDEF2 : MMDX_SKIN_BDEF4);
+    std::memcpy(ids, p.ids.data(), size_t(p.nv) * 16);
+    std::memcpy(weights, p.wts.data(), size_t(p.nv) * 16);
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_model_slot_weights(mmdx_model_t m, const float *rates, float *out) {
+    if (!m || (m->plan.ns && (!rates || !out))) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    flatten_slot_weights(m->plan, rates, out);
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_model_set_stream(mmdx_model_t m, void *hip_stream) {
+    if (!m) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL");
+    if (m->device < 0) return fail(MMDX_ERR_NO_DEVICE, "host-only model");
+    m->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->own_stream;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
+    if (!m || !a) return fail(MMDX_ERR_INVALID_ARGUMENT, "model / args is NULL");
+    if (a->struct_size != sizeof(mmdx_deform_args))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_deform_args.struct_size mismatch");
+    if (m->device < 0)
+        return fail(MMDX_ERR_NO_DEVICE, "model was created with MMDX_CREATE_HOST_ONLY: nothing to run on "
+                                        "(this engine has no CPU fallback)");
+    const Plan &p = m->plan;
+    const uint32_t ni = a->n_instances, layout = a->out_layout;
+    if (ni == 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "n_instances must be >= 1");
+    if (layout > MMDX_OUT_SOA_POS16) return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown out_layout");
+    if (p.f16 != (layout == MMDX_OUT_SOA_POS16))
+        return fail(MMDX_ERR_UNSUPPORTED, "MMDX_OUT_SOA_POS16 goes with MMDX_CREATE_F16_POSITIONS models "
+                                          "(and only with them)");
+    if (!a->palettes || !a->out_a || (layout != MMDX_OUT_VERTEX32 && !a->out_b))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "palettes / out_a / out_b is NULL");
+    if (p.ns && !a->morph_weights) return fail(MMDX_ERR_INVALID_ARGUMENT, "morph_weights is NULL");
+    const bool shared = (a->flags & MMDX_WEIGHTS_SHARED) != 0 || ni == 1;
+    const uint64_t nvi = uint64_t(ni) * p.nv;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+
+    DeformParams dp;
+    std::memset(&dp, 0, sizeof(dp));
+    dp.tiles = static_cast<const TileHdr *>(m->tiles.ptr);
+    dp.spos = m->spos.ptr;
+    dp.snrm = static_cast<const float *>(m->snrm.ptr);
+    dp.suv = static_cast<const float *>(m->suv.ptr);
+    dp.perm = static_cast<const uint16_t *>(m->perm.ptr);
+    dp.skin1 = static_cast<const uint16_t *>(m->skin1.ptr);
+    dp.skin2_ids = static_cast<const uint32_t *>(m->skin2_ids.ptr);
+    dp.skin2_w = static_cast<const float *>(m->skin2_w.ptr);
+    dp.skin4_ids = static_cast<const uint2 *>(m->skin4_ids.ptr);
+    dp.skin4_w = static_cast<const float4 *>(m->skin4_w.ptr);
+    dp.bone_list = static_cast<const uint32_t *>(m->bone_list.ptr);
+    dp.row_ptr = static_cast<const uint32_t *>(m->row_ptr.ptr);
+    dp.entries = m->entries.ptr;
+    dp.nv = p.nv; dp.nb = p.nb; dp.ns = p.ns; dp.ni = ni;
+    dp.pos_scale = a->pos_scale;
+    dp.pal_stride = p.max_tile_bones * 3;
+
+    // ---- palettes -------------------------------------------------------------------------------
+    const size_t pal_bytes = size_t(ni) * p.nb * 64;
+    if (a->flags & MMDX_PALETTE_ON_DEVICE) {
+        if (reinterpret_cast<uintptr_t>(a->palettes) & 15)
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "device palettes must be 16-byte aligned");
+        dp.palettes = a->palettes;
+    } else {
+        HIP_TRY(m->pal.ensure(pal_bytes));
+        HIP_TRY(hipMemcpyAsync(m->pal.ptr, a->palettes, pal_bytes, hipMemcpyHostToDevice, st));
+        dp.palettes = static_cast<const float *>(m->pal.ptr);
+    }
+
+    // ---- morph mode + slot weights ----------------------------------------------------------------
+    int morph = kMorphNone;
+    if (p.ns) morph = shared ? (ni == 1 ? kMorphFused1 : kMorphShared) : kMorphFused4;
+    if (morph != kMorphNone) {
+        const uint32_t niw = shared ? 1u : ni;
+        const float *rates_dev;
+        if (a->flags & MMDX_WEIGHTS_ON_DEVICE) {
+            rates_dev = a->morph_weights;
+        } else {
+            HIP_TRY(m->rates.ensure(size_t(niw) * p.nm * 4));
+            HIP_TRY(hipMemcpyAsync(m->rates.ptr, a->morph_weights, size_t(niw) * p.nm * 4,
+                                   hipMemcpyHostToDevice, st));
+            rates_dev = static_cast<const float *>(m->rates.ptr);
+        }
+        FlattenParams f;
+        f.rates = rates_dev;
+        f.slot_top = static_cast<const uint32_t *>(m->slot_top.ptr);
+        f.chain_off = static_cast<const uint32_t *>(m->chain_off.ptr);
+        f.chain_rate = static_cast<const float *>(m->chain_rate.ptr);
+        f.nm = p.nm; f.ns = p.ns; f.niw = niw;
+        f.quad = morph == kMorphFused4 ? 1u : 0u;
+        const size_t rows = f.quad ? size_t((niw + 3) / 4) * 4 : niw;
+        HIP_TRY(m->wslot.ensure(rows * p.ns * 4));
+        f.out = static_cast<float *>(m->wslot.ptr);
+        if (m->profile) HIP_TRY(hipEventRecord(m->ev_m0, st));
+        HIP_TRY(launch_flatten(f, st));
+        dp.wslot = f.out;
+        dp.morphed = static_cast<float *>(m->morphed.ptr);
+        if (morph == kMorphShared) HIP_TRY(launch_morph_apply(p.f16, dp, st));
+        if (m->profile) HIP_TRY(hipEventRecord(m->ev_m1, st));
+    }
+    m->prof_morph = m->profile && morph != kMorphNone;
+
+    // ---- outputs ---------------------------------------------------------------------------------
+    const size_t bytes_a = out_bytes_a(layout, nvi), bytes_b = out_bytes_b(layout, nvi);
+    const bool out_dev = (a->flags & MMDX_OUT_ON_DEVICE) != 0;
+    if (out_dev) {
+        dp.out_a = a->out_a; dp.out_b = a->out_b;
+    } else {
+        HIP_TRY(m->out_a.ensure(bytes_a));
+        if (bytes_b) HIP_TRY(m->out_b.ensure(bytes_b));
+        dp.out_a = m->out_a.ptr; dp.out_b = m->out_b.ptr;
+    }
+    dp.out_aligned = ((reinterpret_cast<uintptr_t>(dp.out_a) | reinterpret_cast<uintptr_t>(dp.out_b)) & 15) == 0;
+
+    // ---- group size (instances per workgroup) from the LDS budget ---------------------------------
+    const uint32_t gmin = morph == kMorphFused4 ? 4u : 1u;
+    uint32_t group = gmin;
+    if (morph != kMorphFused1) {
+        const uint32_t target = uint32_t(env_int("MMDX_LDS_TARGET", 48 * 1024));
+        uint32_t so, wo;
+        const size_t fixed = deform_lds_bytes(layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);
+        const size_t per = size_t(p.max_tile_bones) * 48 + (morph == kMorphFused4 ? size_t(p.ns) * 4 : 0);
+        uint32_t g = target > fixed ? uint32_t((target - fixed) / per) : 0u;
+        g = std::min(g, 32u);
+        g = std::max(g / gmin * gmin, gmin);
+        const uint32_t ni_up = (ni + gmin - 1) / gmin * gmin;
+        g = std::min(g, ni_up);
+        // keep the grid large enough to fill 256 CUs several times over
+        while (g > gmin && uint64_t(p.ntiles) * ((ni + g - 1) / g) < 2048) {
+            const uint32_t half = std::max((g / 2) / gmin * gmin, gmin);
+            if (half == g) break;
+            g = half;
+        }
+        group = std::max(g, gmin);
+        const int forced = env_int("MMDX_GROUP", 0);
+        if (forced > 0) group = std::max(uint32_t(forced) / gmin * gmin, gmin);
+    }
+    dp.group = group;
+    const size_t lds = deform_lds_bytes(layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off);
+    if (lds > 160 * 1024)
+        return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(lds) + " bytes of LDS (> 160 KiB): "
+                                          "too many distinct bones in one vertex tile / too many morph slots");
+
+    if (m->profile) HIP_TRY(hipEventRecord(m->ev_s0, st));
+    HIP_TRY(launch_deform(int(layout), morph, p.f16, dp, p.ntiles, lds, st));
+    if (m->profile) {
+        HIP_TRY(hipEventRecord(m->ev_s1, st));
+        m->prof_valid = true;
+    }
+
+    if (!out_dev) {
+        HIP_TRY(hipMemcpyAsync(a->out_a, dp.out_a, bytes_a, hipMemcpyDeviceToHost, st));
+        if (bytes_b) HIP_TRY(hipMemcpyAsync(a->out_b, dp.out_b, bytes_b, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else if (!(a->flags & MMDX_PALETTE_ON_DEVICE) ||
+               (morph != kMorphNone && !(a->flags & MMDX_WEIGHTS_ON_DEVICE))) {
+        // borrowed host inputs must be consumed before we return
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_deform(mmdx_model_t m, const float *w, const float *palette, float *out_pos,
+                        float *out_nrm) {
+    mmdx_deform_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.struct_size = sizeof(a);
+    a.n_instances = 1;
+    a.out_layout = MMDX_OUT_SOA;
+    a.morph_weights = w; a.palettes = palette;
+    a.out_a = out_pos; a.out_b = out_nrm;
+    a.pos_scale = 1.0f;
+    return mmdx_deform_batched(m, &a);
+}
+
+mmdx_status mmdx_deform_vertex32(mmdx_model_t m, const float *w, const float *palette,
+                                 float pos_scale, void *out_vertices) {
+    mmdx_deform_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.struct_size = sizeof(a);
+    a.n_instances = 1;
+    a.out_layout = MMDX_OUT_VERTEX32;
+    a.morph_weights = w; a.palettes = palette;
+    a.out_a = out_vertices;
+    a.pos_scale = pos_scale;
+    return mmdx_deform_batched(m, &a);
+}
+
+mmdx_status mmdx_sync(mmdx_model_t m) {
+    if (!m) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL");
+    if (m->device < 0) return fail(MMDX_ERR_NO_DEVICE, "host-only model");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_timer_start(mmdx_model_t m) {
+    if (!m || m->device < 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
+    HIP_TRY(hipEventRecord(m->ev_t0, m->stream));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_timer_stop(mmdx_model_t m, float *ms) {
+    if (!m || m->device < 0 || !ms) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
+    HIP_TRY(hipEventRecord(m->ev_t1, m->stream));
+    HIP_TRY(hipEventSynchronize(m->ev_t1));
+    HIP_TRY(hipEventElapsedTime(ms, m->ev_t0, m->ev_t1));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_profile_enable(mmdx_model_t m, int32_t enabled) {
+    if (!m || m->device < 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
+    m->profile = enabled != 0;
+    m->prof_valid = false;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_profile_last(mmdx_model_t m, float *skin_ms, float *morph_ms) {
+    if (!m || m->device < 0 || !skin_ms || !morph_ms)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or host-only model");
+    if (!m->prof_valid) return fail(MMDX_ERR_INVALID_ARGUMENT, "no profiled call yet");
+    HIP_TRY(hipEventSynchronize(m->ev_s1));
+    HIP_TRY(hipEventElapsedTime(skin_ms, m->ev_s0, m->ev_s1));
+    *morph_ms = 0.f;
+    if (m->prof_morph) HIP_TRY(hipEventElapsedTime(morph_ms, m->ev_m0, m->ev_m1));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_device_malloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(MMDX_ERR_INVALID_ARGUMENT, "ptr is NULL");
+    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipMalloc(ptr, bytes ? bytes : 16));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_device_free(void *ptr) {
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_device_memset(void *dst, int value, size_t bytes) {
+    HIP_TRY(hipMemset(dst, value, bytes));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_device_synchronize(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return MMDX_OK;
+}
+
+static mmdx_status bench_stream_op(void *dst, const void *src, size_t bytes, int32_t iters, float *avg_ms) {
+    if (!dst || !avg_ms || iters <= 0 || bytes < 16) return fail(MMDX_ERR_INVALID_ARGUMENT, "bad argument");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipError_t e = src ? launch_copy(dst, src, bytes, nullptr) : launch_fill(dst, bytes, nullptr);  // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && e == hipSuccess; ++i)
+        e = src ? launch_copy(dst, src, bytes, nullptr) : launch_fill(dst, bytes, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return hip_fail(e, "bench stream op");
+    *avg_ms = ms / float(iters);
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_bench_copy(void *dst, const void *src, size_t bytes, int32_t iters, float *avg_ms) {
+    if (!src) return fail(MMDX_ERR_INVALID_ARGUMENT, "src is NULL");
+    return bench_stream_op(dst, src, bytes, iters, avg_ms);
+}
+
+mmdx_status mmdx_bench_fill(void *dst, size_t bytes, int32_t iters, float *avg_ms) {
+    return bench_stream_op(dst, nullptr, bytes, iters, avg_ms);
+}
+
+}  // extern "C"

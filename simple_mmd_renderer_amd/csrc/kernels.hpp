@@ -1,0 +1,74 @@
+// kernels.hpp -- launch interface between the C-ABI host code (api.cpp) and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.hpp"
+
+namespace mmdx {
+
+// Morph handling of one deform launch
+enum : int {
+    kMorphNone = 0,     // model has no vertex-morph slot
+    kMorphShared = 1,   // positions come from the `morphed` buffer written by morph_apply (crowd
+                        // with one shared facial state: the morph pass runs once per call)
+    kMorphFused1 = 2,   // per-instance weights, one instance at a time (single deform)
+    kMorphFused4 = 3    // per-instance weights, 4 instances share one pass over a CSR row
+};
+
+struct DeformParams {
+    // static streams (HBM, uploaded once by mmdx_model_create)
+    const TileHdr *tiles;
+    const void *spos;            // f32 [NV][3]  |  f16 mode: u16 [NV][4]
+    const float *snrm;           // [NV][3]
+    const float *suv;            // [NV][2]
+    const uint16_t *perm;        // [NV]
+    const uint16_t *skin1;
+    const uint32_t *skin2_ids;
+    const float *skin2_w;
+    const uint2 *skin4_ids;
+    const float4 *skin4_w;
+    const uint32_t *bone_list;
+    const uint32_t *row_ptr;     // [NV+1]
+    const void *entries;         // float4 [NE]  |  f16 mode: uint2 [NE]
+    // per call
+    const float *palettes;       // [NI][NB][16] device
+    const float *wslot;          // kMorphFused1: f32 [NS] per instance (stride ns)
+                                 // kMorphFused4: float4 [ceil(NI/4)][NS] (instance quads)
+                                 // morph_apply : f32 [NS]
+    float *morphed;              // f32 [NV][3] sorted order (kMorphShared)
+    void *out_a;
+    void *out_b;
+    uint32_t nv, nb, ns, ni;
+    uint32_t group;              // instances per workgroup (multiple of 4 for kMorphFused4)
+    uint32_t pal_stride;         // float4 per instance in LDS (= max_tile_bones * 3)
+    uint32_t stage_off;          // byte offsets inside dynamic LDS
+    uint32_t w_off;
+    float pos_scale;
+    uint32_t out_aligned;        // out_a and out_b are 16-byte aligned
+};
+
+struct FlattenParams {
+    const float *rates;          // [NIw][NM] device
+    const uint32_t *slot_top, *chain_off;
+    const float *chain_rate;
+    float *out;
+    uint32_t nm, ns, niw;
+    uint32_t quad;               // 1: write float4 [ceil(NIw/4)][NS] instance quads (pad lanes = 0)
+};
+
+// Bytes of dynamic LDS the deform kernel needs for (layout, morph mode, group).
+size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
+                        uint32_t *stage_off, uint32_t *w_off);
+
+hipError_t launch_deform(int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles,
+                         size_t lds_bytes, hipStream_t stream);
+hipError_t launch_morph_apply(bool f16, const DeformParams &p, hipStream_t stream);
+hipError_t launch_flatten(const FlattenParams &p, hipStream_t stream);
+hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream);
+hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
+hipError_t prepare_kernels();  // raise the dynamic-LDS limit of every deform variant (once)
+
+}  // namespace mmdx

@@ -1,0 +1,208 @@
+"""Synthetic PMX-like models, morph weights and bone palettes for tests and bench.
+
+The reference ships no .pmx/.vmd asset, so every input is generated here,
+deterministically, following the recipe of SURVEY.md section 8d: positions U(-10,10)xU(0,20)xU(-2,2),
+unit normals, deform-type mix BDEF1 20 % / BDEF2 50 % / BDEF4 25 % / SDEF 5 % assigned i.i.d.
+per vertex, bone ids drawn from a window of 16 consecutive ids around v*NB/NV, BDEF4 weights
+normalised U(0.01,1)^4, vertex morphs of K distinct vertices with offsets U(-0.5,0.5)^3, and rigid
+per-frame palettes from a forward-kinematics pass over a random hierarchy.
+
+A model is a `FlatModel`: the flat, SoA description that crosses the C ABI (include/mmdx.h
+`mmdx_model_desc`) -- the same information the reference keeps in mmd::Model's vertex store,
+SkinningOperator union and Morph lists (L/model/model.inl:21-104, :334-517, :719-726).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+# PMX / libmmd tag values (L/model/model.inl:23-28, :488-498)
+BDEF1, BDEF2, BDEF4, SDEF = 0, 1, 2, 3
+MORPH_GROUP, MORPH_VERTEX, MORPH_BONE, MORPH_UV, MORPH_MATERIAL = 0, 1, 2, 3, 8
+
+
+@dataclass
+class FlatModel:
+    positions: np.ndarray      # f32 [NV,3]
+    normals: np.ndarray        # f32 [NV,3]
+    uvs: np.ndarray            # f32 [NV,2]
+    skin_type: np.ndarray      # i32 [NV]   raw tag (unknown values take the BDEF2 branch)
+    bone_ids: np.ndarray       # i32 [NV,4]
+    bone_weights: np.ndarray   # f32 [NV,4] (BDEF2/SDEF: [:,0])
+    bone_pos: np.ndarray       # f32 [NB,3] rest positions
+    bone_parent: np.ndarray    # i32 [NB]   -1 = root
+    morph_type: np.ndarray     # i32 [NM]
+    morph_off: np.ndarray      # u32 [NM+1] entry ranges
+    morph_index: np.ndarray    # u32 [E]    vertex (vertex morph) / morph (group) / bone / ...
+    morph_value: np.ndarray    # f32 [E,3]  offset (vertex morph) / (rate,0,0) (group) / translation
+    sdef: Optional[np.ndarray] = None   # f32 [NV,9] C,R0,R1 (stored, never evaluated: see DESIGN.md)
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def nv(self) -> int:
+        return int(self.positions.shape[0])
+
+    @property
+    def nb(self) -> int:
+        return int(self.bone_pos.shape[0])
+
+    @property
+    def nm(self) -> int:
+        return int(self.morph_type.shape[0])
+
+    def copy(self) -> "FlatModel":
+        kw = {}
+        for k, v in self.__dict__.items():
+            kw[k] = v.copy() if isinstance(v, np.ndarray) else (dict(v) if isinstance(v, dict) else v)
+        return FlatModel(**kw)
+
+
+def checksum64(a: np.ndarray) -> int:
+    """Order-sensitive 64-bit checksum of an array's bytes (position-salted multiply-xor fold).
+    Used for the checksum-only fixtures (600-frame config 1) and for full-size GPU runs where
+    shipping every output would be too much."""
+    b = np.ascontiguousarray(a).ravel().view(np.uint8)
+    pad = (-b.size) % 8
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, np.uint8)])
+    w = b.view(np.uint64)
+    idx = np.arange(1, w.size + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        mixed = (w ^ (idx * np.uint64(0x9E3779B97F4A7C15))) * np.uint64(0x100000001B3)
+        mixed ^= mixed >> np.uint64(29)
+        return int(np.bitwise_xor.reduce(mixed) ^ np.uint64(w.size))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def make_morphs(rng, nv: int, nm: int, k: int):
+    """nm vertex morphs, each of k distinct vertices (file order = draw order)."""
+    k = min(k, nv)
+    morph_type = np.full(nm, MORPH_VERTEX, np.int32)
+    morph_off = (np.arange(nm + 1, dtype=np.uint64) * k).astype(np.uint32)
+    idx = np.empty((nm, k), np.uint32)
+    for m in range(nm):
+        if k * 8 < nv:
+            # rejection-free partial shuffle is overkill: draw with margin, keep first k uniques
+            while True:
+                c = rng.randint(0, nv, size=int(k * 1.2) + 16)
+                _, first = np.unique(c, return_index=True)
+                if first.size >= k:
+                    idx[m] = c[np.sort(first)[:k]]
+                    break
+        else:
+            idx[m] = rng.permutation(nv)[:k]
+    val = _f32(rng.uniform(-0.5, 0.5, size=(nm * k, 3)))
+    return morph_type, morph_off, idx.reshape(-1), val
+
+
+def make_model(nv: int, nb: int, nm: int, k: int, seed: int,
+               mix=(0.20, 0.50, 0.25, 0.05), window: int = 16) -> FlatModel:
+    rng = np.random.RandomState(seed)
+    pos = np.stack([rng.uniform(-10, 10, nv), rng.uniform(0, 20, nv), rng.uniform(-2, 2, nv)], 1)
+    nrm = rng.uniform(-1, 1, size=(nv, 3))
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-6)
+    uv = rng.uniform(0, 1, size=(nv, 2))
+    bone_pos = np.stack([rng.uniform(-10, 10, nb), rng.uniform(0, 20, nb), rng.uniform(-1, 1, nb)], 1)
+    parent = np.full(nb, -1, np.int32)
+    for b in range(1, nb):
+        parent[b] = rng.randint(0, b)
+    u = rng.uniform(0, 1, nv)
+    edges = np.cumsum(mix)
+    skin_type = np.where(u < edges[0], BDEF1,
+                         np.where(u < edges[1], BDEF2,
+                                  np.where(u < edges[2], BDEF4, SDEF))).astype(np.int32)
+    win = min(window, nb)
+    centre = (np.arange(nv, dtype=np.int64) * nb) // max(nv, 1)
+    lo = np.clip(centre - win // 2, 0, nb - win)
+    ids = (lo[:, None] + rng.randint(0, win, size=(nv, 4))).astype(np.int32)
+    w = np.zeros((nv, 4), np.float32)
+    w2 = rng.uniform(0.01, 0.99, nv).astype(np.float32)
+    w4 = rng.uniform(0.01, 1.0, size=(nv, 4))
+    w4 = (w4 / w4.sum(1, keepdims=True)).astype(np.float32)
+    is4 = skin_type == BDEF4
+    is2 = (skin_type == BDEF2) | (skin_type == SDEF)
+    w[is4] = w4[is4]
+    w[is2, 0] = w2[is2]
+    sdef = _f32(rng.uniform(-1, 1, size=(nv, 9)))
+    mt, mo, mi, mv = make_morphs(rng, nv, nm, k)
+    return FlatModel(_f32(pos), _f32(nrm), _f32(uv), skin_type, np.ascontiguousarray(ids), w,
+                     _f32(bone_pos), parent, mt, mo, mi, mv, sdef,
+                     meta=dict(nv=nv, nb=nb, nm=nm, k=k, seed=seed))
+
+
+def morph_weights(nm: int, frame) -> np.ndarray:
+    """weight_m(frame) = clip(0.5 + 0.5 sin(2 pi (frame/90 + m/NM)), 0, 1); frame may be an array."""
+    frame = np.atleast_1d(np.asarray(frame, np.float64))
+    m = np.arange(nm, dtype=np.float64)
+    w = 0.5 + 0.5 * np.sin(2 * np.pi * (frame[:, None] / 90.0 + m[None, :] / max(nm, 1)))
+    return np.clip(w, 0.0, 1.0).astype(np.float32)
+
+
+def _axis_angle_to_mat(axis, angle):
+    """Row-vector rotation matrices [...,3,3] (y = x . R)."""
+    axis = axis / np.maximum(np.linalg.norm(axis, axis=-1, keepdims=True), 1e-9)
+    x, y, z = axis[..., 0], axis[..., 1], axis[..., 2]
+    c, s = np.cos(angle), np.sin(angle)
+    t = 1 - c
+    r = np.empty(axis.shape[:-1] + (3, 3))
+    r[..., 0, 0] = t * x * x + c
+    r[..., 0, 1] = t * x * y + s * z
+    r[..., 0, 2] = t * x * z - s * y
+    r[..., 1, 0] = t * x * y - s * z
+    r[..., 1, 1] = t * y * y + c
+    r[..., 1, 2] = t * y * z + s * x
+    r[..., 2, 0] = t * x * z + s * y
+    r[..., 2, 1] = t * y * z - s * x
+    r[..., 2, 2] = t * z * z + c
+    return r
+
+
+def make_palettes(model: FlatModel, frames, seed: int = 7) -> np.ndarray:
+    """Rigid skinning matrices f32 [len(frames), NB, 16], row-vector convention, translation in
+    elements 12..14 -- the layout of Poser::BoneImage::skinning_matrix_ (L/motion/poser.inl:96,
+    L/util/math.inl:383-395).  skinning = translate(-rest) x world(bone), world = local x world(parent)
+    (the shape of UpdateBoneSkinningMatrix, L/motion/poser_impl.inl:320-326; our own FK, float64)."""
+    frames = np.atleast_1d(np.asarray(frames, np.float64))
+    nf, nb = frames.shape[0], model.nb
+    rng = np.random.RandomState(seed)
+    axis = rng.uniform(-1, 1, size=(nb, 3))
+    trans = rng.uniform(-0.2, 0.2, size=(nb, 3))
+    b = np.arange(nb, dtype=np.float64)
+    angle = 0.5 * np.sin(2 * np.pi * (frames[:, None] / 60.0 + b[None, :] / nb))   # [nf, nb]
+    rot = _axis_angle_to_mat(np.broadcast_to(axis, (nf, nb, 3)), angle)             # [nf, nb,3,3]
+    rest = model.bone_pos.astype(np.float64)
+    world = np.zeros((nf, nb, 4, 4))
+    out = np.zeros((nf, nb, 4, 4))
+    for i in range(nb):
+        p = int(model.bone_parent[i])
+        local = np.zeros((nf, 4, 4))
+        local[:, :3, :3] = rot[:, i]
+        off = rest[i] - (rest[p] if p >= 0 else 0.0)
+        local[:, 3, :3] = trans[i] + off
+        local[:, 3, 3] = 1.0
+        world[:, i] = local @ world[:, p] if p >= 0 else local
+        g = np.eye(4)
+        g[3, :3] = -rest[i]
+        out[:, i] = g @ world[:, i]
+    return np.ascontiguousarray(out.reshape(nf, nb, 16), dtype=np.float32)
+
+
+# ---- the five BASELINE.json configs ----------------------------------------
+CONFIGS = {
+    "config1_20k": dict(nv=20000, nb=150, nm=30, k=500, seed=20001),
+    "config2_50k": dict(nv=50000, nb=300, nm=200, k=2048, seed=50002),
+    "config3_crowd": dict(nv=50000, nb=300, nm=200, k=2048, seed=50002, instances=1024),
+    "config5_256k": dict(nv=262144, nb=512, nm=1024, k=4096, seed=262005),
+}
+
+
+def make_config(name: str) -> FlatModel:
+    c = CONFIGS[name]
+    m = make_model(c["nv"], c["nb"], c["nm"], c["k"], c["seed"])
+    m.meta["config"] = name
+    return m

@@ -1,0 +1,290 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against (a) the golden vectors produced by
+the real libmmd and (b) the C restatement on seeded inputs.  Bit-exact: integer/index work AND the
+f32 arithmetic (kernels are built with -ffp-contract=off and keep the reference's operation order),
+so no tolerance is needed; the fp16 bandwidth variant is compared against the f32 oracle on
+f16-quantised inputs with its positions rounded to f16 once -- also bit-exact."""
+import numpy as np
+import pytest
+
+from simple_mmd_renderer_amd import _capi as api
+from simple_mmd_renderer_amd import synth
+from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer, Poser, device_count
+from simple_mmd_renderer_amd.synth import BDEF1, BDEF2, BDEF4, MORPH_GROUP, MORPH_VERTEX
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(hip_lib):
+    assert device_count() >= 1, "no HIP device visible: the GPU tests must run on the MI355X box"
+
+
+def oracle_expect(oracle, m, rates, pal, normalize=True):
+    skin = oracle.normalize(m) if normalize else None
+    pos, nrm = oracle.skin(m, pal, oracle.morph(m, rates), skin)
+    return pos, nrm
+
+
+# ---- golden vectors (reference's own outputs) ------------------------------------------------------
+@pytest.mark.parametrize("name", gu.fixture_names())
+def test_golden_single_deform(name):
+    m, exp = gu.load(name)
+    with DeformModel(m, normalize=exp["normalize"]) as dm:
+        for f in range(exp["rates"].shape[0]):
+            pos, nrm = dm.deform(exp["rates"][f], exp["palette"][f])
+            gu.assert_bits_equal(pos, exp["expect_pos"][f], f"{name}[{f}] pos")
+            gu.assert_bits_equal(nrm, exp["expect_nrm"][f], f"{name}[{f}] nrm")
+            v32 = dm.deform_vertex32(exp["rates"][f], exp["palette"][f], 0.1)
+            gu.assert_bits_equal(v32, exp["expect_v32"][f], f"{name}[{f}] vertex32")
+
+
+@pytest.mark.parametrize("name", ["g07_vertex_morph", "g08_group_morph", "g11_solved_palette",
+                                  "g12_mini_model", "g14_denormals"])
+@pytest.mark.parametrize("layout", [api.OUT_SOA, api.OUT_VERTEX32])
+def test_golden_batched_frames_as_instances(name, layout):
+    """Frames are independent given palettes + rates: run all frames of a fixture as one batched call
+    with per-instance morph weights (fused morph gather, 4 instances per CSR pass)."""
+    m, exp = gu.load(name)
+    nf = exp["rates"].shape[0]
+    reps = 3                                    # > 4 instances, ragged last quad
+    rates = np.tile(exp["rates"], (reps, 1))
+    pals = np.tile(exp["palette"], (reps, 1, 1))
+    with DeformModel(m, normalize=exp["normalize"]) as dm:
+        out = dm.deform_batched(rates, pals, layout=layout, pos_scale=0.1 if layout == api.OUT_VERTEX32 else 1.0)
+        for i in range(nf * reps):
+            f = i % nf
+            if layout == api.OUT_SOA:
+                gu.assert_bits_equal(out[0][i], exp["expect_pos"][f], f"{name} inst {i} pos")
+                gu.assert_bits_equal(out[1][i], exp["expect_nrm"][f], f"{name} inst {i} nrm")
+            else:
+                gu.assert_bits_equal(out[i], exp["expect_v32"][f], f"{name} inst {i} v32")
+
+
+def test_golden_shared_weights_crowd():
+    """Crowd form: one morph state for all instances (separate morph pass), per-instance palettes."""
+    m, exp = gu.load("g12_mini_model")
+    nf = exp["rates"].shape[0]
+    with DeformModel(m, normalize=True) as dm:
+        for f in range(nf):
+            # every frame's palette as an instance, all with frame f's morph weights
+            pos, nrm = dm.deform_batched(exp["rates"][f], exp["palette"], shared_weights=True)
+            gu.assert_bits_equal(pos[f], exp["expect_pos"][f], "pos")
+            gu.assert_bits_equal(nrm[f], exp["expect_nrm"][f], "nrm")
+
+
+def test_config1_600_frames_checksums():
+    """configs[0] through the GPU path: per-frame checksums recorded from libmmd."""
+    import os
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "g13_config1_checksums.npz"))
+    m = synth.make_config("config1_20k")
+    frames = z["frames"]
+    rates = synth.morph_weights(m.nm, frames)
+    pals = synth.make_palettes(m, frames)
+    with DeformModel(m) as dm:
+        for b in range(0, 600, 100):            # 100 frames per batched call
+            sl = slice(b, b + 100)
+            pos, nrm = dm.deform_batched(rates[sl], pals[sl])
+            v32 = dm.deform_batched(rates[sl], pals[sl], layout=api.OUT_VERTEX32, pos_scale=0.1)
+            for i in range(100):
+                got = (synth.checksum64(pos[i]), synth.checksum64(nrm[i]), synth.checksum64(v32[i]))
+                assert got == tuple(int(x) for x in z["checksums"][b + i]), f"frame {b + i}"
+
+
+# ---- seeded inputs vs the C restatement ------------------------------------------------------------
+@pytest.mark.parametrize("nv", [1, 2, 63, 64, 255, 256, 257, 511, 512, 513, 1000, 1025, 4099])
+def test_ragged_sizes_and_unaligned_rows(oracle, nv):
+    """Every tail shape of the 512-vertex tile, odd NV (output rows of instance i start at i*NV*12
+    bytes: exercises the unaligned head/tail of the staged copy-out)."""
+    nb = 1 if nv == 1 else 17
+    m = synth.make_model(nv, nb, 3, min(nv, 40), seed=1000 + nv)
+    ni = 5
+    rates = synth.morph_weights(m.nm, np.arange(ni) * 7)
+    pals = synth.make_palettes(m, np.arange(ni) * 3)
+    with DeformModel(m) as dm:
+        pos, nrm = dm.deform_batched(rates, pals)
+        v32 = dm.deform_batched(rates, pals, layout=api.OUT_VERTEX32, pos_scale=0.1)
+        spos, snrm = dm.deform_batched(rates[2], pals, shared_weights=True)
+        for i in range(ni):
+            ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+            gu.assert_bits_equal(pos[i], ep, f"nv={nv} inst {i} pos")
+            gu.assert_bits_equal(nrm[i], en, f"nv={nv} inst {i} nrm")
+            gu.assert_bits_equal(v32[i], oracle.repack32(m, ep, en, 0.1), f"nv={nv} inst {i} v32")
+            sp, sn = oracle_expect(oracle, m, rates[2], pals[i])
+            gu.assert_bits_equal(spos[i], sp, f"nv={nv} shared inst {i} pos")
+            gu.assert_bits_equal(snrm[i], sn, f"nv={nv} shared inst {i} nrm")
+
+
+@pytest.mark.parametrize("mix", [(1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1),
+                                 (0.02, 0.02, 0.95, 0.01), (0.25, 0.25, 0.25, 0.25)])
+def test_class_mixes(oracle, mix):
+    m = synth.make_model(3000, 90, 6, 300, seed=55, mix=mix)
+    rates = synth.morph_weights(m.nm, [4, 50])
+    pals = synth.make_palettes(m, [4, 50])
+    with DeformModel(m) as dm:
+        pos, nrm = dm.deform_batched(rates, pals)
+        for i in range(2):
+            ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+            gu.assert_bits_equal(pos[i], ep, "pos")
+            gu.assert_bits_equal(nrm[i], en, "nrm")
+
+
+def test_many_bones_per_tile(oracle):
+    """Bone ids spread over the whole skeleton: every tile needs (nearly) all 512 bones in LDS."""
+    m = synth.make_model(2048, 512, 4, 100, seed=77, window=512)
+    rates = synth.morph_weights(m.nm, [1, 2, 3])
+    pals = synth.make_palettes(m, [1, 2, 3])
+    with DeformModel(m) as dm:
+        assert dm.info.max_tile_bones > 400
+        pos, nrm = dm.deform_batched(rates, pals)
+        for i in range(3):
+            ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+            gu.assert_bits_equal(pos[i], ep, "pos")
+            gu.assert_bits_equal(nrm[i], en, "nrm")
+
+
+def test_no_morph_model_and_empty_rows(oracle):
+    m = synth.make_model(700, 12, 1, 1, seed=5)
+    m.morph_type = np.zeros(0, np.int32)
+    m.morph_off = np.zeros(1, np.uint32)
+    m.morph_index = np.zeros(0, np.uint32)
+    m.morph_value = np.zeros((0, 3), np.float32)
+    m.positions[::7] = np.float32(-0.0)
+    pal = synth.make_palettes(m, [9])[0]
+    with DeformModel(m) as dm:
+        pos, nrm = dm.deform(np.zeros(0, np.float32), pal)
+        ep, en = oracle_expect(oracle, m, np.zeros(0, np.float32), pal)
+        gu.assert_bits_equal(pos, ep, "pos")
+        gu.assert_bits_equal(nrm, en, "nrm")
+
+
+def test_device_resident_io_matches_host_io(oracle):
+    """The bench path: palettes, weights and outputs all resident in HBM."""
+    m = synth.make_model(5000, 120, 10, 400, seed=31)
+    ni = 37
+    rates = synth.morph_weights(m.nm, np.arange(ni))
+    pals = synth.make_palettes(m, np.arange(ni))
+    with DeformModel(m) as dm:
+        d_pal = DeviceBuffer.from_numpy(pals)
+        d_w = DeviceBuffer.from_numpy(rates)
+        sa, sb = dm.out_sizes(api.OUT_SOA, ni)
+        d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+        flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+        dm.sync()
+        pos = d_a.download((ni, m.nv, 3), np.float32)
+        nrm = d_b.download((ni, m.nv, 3), np.float32)
+        for i in (0, 1, 17, 36):
+            ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+            gu.assert_bits_equal(pos[i], ep, "pos")
+            gu.assert_bits_equal(nrm[i], en, "nrm")
+        # shared weights, device resident
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA,
+                              flags | api.WEIGHTS_SHARED)
+        dm.sync()
+        pos = d_a.download((ni, m.nv, 3), np.float32)
+        ep, en = oracle_expect(oracle, m, rates[0], pals[20])
+        gu.assert_bits_equal(pos[20], ep, "shared pos")
+        for b in (d_pal, d_w, d_a, d_b):
+            b.free()
+
+
+def test_fp16_position_variant(oracle):
+    """MMDX_CREATE_F16_POSITIONS / MMDX_OUT_SOA_POS16 (config 5): base positions and morph offsets
+    stored as binary16, arithmetic f32, output positions rounded to binary16 once."""
+    m = synth.make_model(3001, 64, 12, 500, seed=808)
+    q = m.copy()
+    q.positions = m.positions.astype(np.float16).astype(np.float32)
+    q.morph_value = m.morph_value.astype(np.float16).astype(np.float32)
+    ni = 6
+    rates = synth.morph_weights(m.nm, np.arange(ni) * 11)
+    pals = synth.make_palettes(m, np.arange(ni) * 5)
+    with DeformModel(m, f16_positions=True) as dm:
+        pos16, nrm = dm.deform_batched(rates, pals, layout=api.OUT_SOA_POS16)
+        spos16, _ = dm.deform_batched(rates[1], pals, layout=api.OUT_SOA_POS16, shared_weights=True)
+        for i in range(ni):
+            ep, en = oracle_expect(oracle, q, rates[i], pals[i])
+            assert np.array_equal(pos16[i].view(np.uint16), ep.astype(np.float16).view(np.uint16)), f"inst {i}"
+            gu.assert_bits_equal(nrm[i], en, "nrm")
+            sp, _ = oracle_expect(oracle, q, rates[1], pals[i])
+            assert np.array_equal(spos16[i].view(np.uint16), sp.astype(np.float16).view(np.uint16))
+        with pytest.raises(api.MmdxError):
+            dm.deform_batched(rates, pals, layout=api.OUT_SOA)
+
+
+def test_poser_mirror_of_reference_interface(oracle):
+    """mmd::Poser-shaped host API: SetMorphPose / palette injection / Deform / pose_image /
+    UpdateDeformedVertices."""
+    m, exp = gu.load("g12_mini_model")
+    poser = Poser(m)
+    for f in range(exp["rates"].shape[0]):
+        poser.ResetPosing()
+        for i, w in enumerate(exp["rates"][f]):
+            poser.SetMorphPose(i, w)
+        poser.SetSkinningMatrices(exp["palette"][f])
+        poser.Deform()
+        gu.assert_bits_equal(poser.pose_image.coordinates, exp["expect_pos"][f], "coordinates")
+        gu.assert_bits_equal(poser.pose_image.normals, exp["expect_nrm"][f], "normals")
+        gu.assert_bits_equal(poser.UpdateDeformedVertices(0.1), exp["expect_v32"][f], "vertex32")
+    poser.close()
+
+
+# ---- full BASELINE sizes: size-independent properties + sampled oracle checks -----------------------
+def test_config3_crowd_full_size_properties(oracle):
+    """1024 x 50 000: (a) instances with identical palettes produce identical outputs, (b) a sample
+    of instances equals the oracle bit for bit, (c) the result does not depend on how instances are
+    grouped into workgroups (batched in one call vs. two half calls)."""
+    m = synth.make_config("config3_crowd")
+    ni = 1024
+    pals = synth.make_palettes(m, np.arange(ni) % 257)       # instances i and i+257 share a palette
+    rates = synth.morph_weights(m.nm, 12)[0]
+    with DeformModel(m) as dm:
+        d_pal = DeviceBuffer.from_numpy(pals)
+        sa, sb = dm.out_sizes(api.OUT_SOA, ni)
+        d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+        d_w = DeviceBuffer.from_numpy(rates)
+        flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+        dm.sync()
+        row = m.nv * 12
+
+        def inst(buf, i):
+            return buf.download((m.nv, 3), np.float32, offset=i * row)
+
+        for i in (0, 3, 100, 511, 766):
+            a, b = inst(d_a, i), inst(d_a, i + 257)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for i in (0, 513, 1023):
+            ep, en = oracle_expect(oracle, m, rates, pals[i])
+            gu.assert_bits_equal(inst(d_a, i), ep, f"inst {i} pos")
+            gu.assert_bits_equal(inst(d_b, i), en, f"inst {i} nrm")
+        full = synth.checksum64(d_a.download((ni * m.nv * 3,), np.float32))
+        # two half-size calls into the same buffers
+        d_a.memset(0)
+        half = ni // 2
+        dm.deform_batched_raw(half, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+        dm.deform_batched_raw(half, d_w.ptr, d_pal.ptr + half * m.nb * 64, d_a.ptr + half * row,
+                              d_b.ptr + half * row, api.OUT_SOA, flags)
+        dm.sync()
+        assert synth.checksum64(d_a.download((ni * m.nv * 3,), np.float32)) == full
+        for b in (d_pal, d_a, d_b, d_w):
+            b.free()
+
+
+def test_config5_fp16_full_size_sample(oracle):
+    """262 144 verts / 512 bones / 1024 morphs x 4096 entries, f16 positions: one frame against the
+    oracle (f16-quantised inputs), plus idempotence of a repeated call."""
+    m = synth.make_config("config5_256k")
+    q = m.copy()
+    q.positions = m.positions.astype(np.float16).astype(np.float32)
+    q.morph_value = m.morph_value.astype(np.float16).astype(np.float32)
+    rates = synth.morph_weights(m.nm, [3, 40])
+    pals = synth.make_palettes(m, [3, 40])
+    with DeformModel(m, f16_positions=True) as dm:
+        pos16, nrm = dm.deform_batched(rates, pals, layout=api.OUT_SOA_POS16)
+        again16, again_n = dm.deform_batched(rates, pals, layout=api.OUT_SOA_POS16)
+        assert np.array_equal(pos16.view(np.uint16), again16.view(np.uint16))
+        for i in range(2):
+            ep, en = oracle_expect(oracle, q, rates[i], pals[i])
+            assert np.array_equal(pos16[i].view(np.uint16), ep.astype(np.float16).view(np.uint16))
+            gu.assert_bits_equal(nrm[i], en, "nrm")
