@@ -320,6 +320,9 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     dp.nv = p.nv; dp.nb = p.nb; dp.ns = p.ns; dp.ni = ni;
     dp.pos_scale = a->pos_scale;
     dp.pal_stride = p.max_tile_bones * 3;
+#ifdef MMDX_ABLATE
+    dp.ablate = uint32_t(env_int("MMDX_ABLATE", 0));
+#endif
 
     // ---- palettes -------------------------------------------------------------------------------
     const size_t pal_bytes = size_t(ni) * p.nb * 64;
@@ -408,7 +411,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
                                           "too many distinct bones in one vertex tile / too many morph slots");
 
     if (m->profile) HIP_TRY(hipEventRecord(m->ev_s0, st));
-    HIP_TRY(launch_deform(int(layout), morph, p.f16, dp, p.ntiles, lds, st));
+    HIP_TRY(launch_deform(env_int("MMDX_THREADS", 512), int(layout), morph, p.f16, dp, p.ntiles, lds, st));
     if (m->profile) {
         HIP_TRY(hipEventRecord(m->ev_s1, st));
         m->prof_valid = true;

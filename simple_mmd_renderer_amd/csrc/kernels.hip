@@ -26,7 +26,6 @@ namespace mmdx {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kVPT = int(kTileVerts) / kThreads;  // vertices per thread (2)
 constexpr float kLerpLo = 1e-7f;                  // float(mmd_math_const_eps)
 constexpr float kLerpHi = 0.99999988f;            // float(1.0 - mmd_math_const_eps)
 constexpr float kMorphEps = 1e-7f;                // rate < 1e-7 (double) <=> rate < 1e-7f
@@ -50,65 +49,149 @@ __device__ __forceinline__ unsigned short f2h(float x) {
     return __builtin_bit_cast(unsigned short, _Float16(x));  // v_cvt_f16_f32, round to nearest even
 }
 
-// ---- matrix blend + mat*vec, reference operation order ------------------------------------------
-// A palette entry in LDS is three float4 "columns": col[j] = (M[0][j], M[1][j], M[2][j], M[3][j]).
-__device__ __forceinline__ float4 blend2_col(const float4 a, const float4 b, float s1, float l) {
-    // (1-l)*a + l*b per element (math_impl.inl:1253 with scalar*M :1004-1023 and M+M :944-963)
-    float4 r;
-    r.x = s1 * a.x + l * b.x;
-    r.y = s1 * a.y + l * b.y;
-    r.z = s1 * a.z + l * b.z;
-    r.w = s1 * a.w + l * b.w;
+// ---- matrix blend + mat*vec, reference operation order, on PACKED f32 pairs ------------------------
+// A wave64 issues one VALU instruction per 4 cycles, so at the occupancy this kernel runs at the
+// number of VALU instructions is what counts: v_pk_mul_f32 / v_pk_add_f32 do two IEEE f32 operations
+// per instruction (each half rounded exactly like v_mul_f32 / v_add_f32).  The palette is laid out
+// in LDS so that every operand pair is an aligned register pair -- no shuffles:
+//     entry = 3 x float4 = {m00 m01 | m10 m11} {m20 m21 | m30 m31} {m02 m12 | m22 m32}
+// (M[r][c], row-vector convention; column 3 of the matrix is never read by the path).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct M12 {
+    v2f p0, p1, p2, p3;  // (m_r0, m_r1) for r = 0..3
+    v2f q0, q1;          // (m02, m12), (m22, m32)
+};
+
+__device__ __forceinline__ M12 load_m12(const float4 *P, uint32_t b) {
+    const float4 A = P[b], B = P[b + 1], C = P[b + 2];
+    M12 m;
+    m.p0 = v2f{A.x, A.y}; m.p1 = v2f{A.z, A.w};
+    m.p2 = v2f{B.x, B.y}; m.p3 = v2f{B.z, B.w};
+    m.q0 = v2f{C.x, C.y}; m.q1 = v2f{C.z, C.w};
+    return m;
+}
+// Lerp(a, b)[l] interior: (1-l)*a + l*b per element (math_impl.inl:1253; s*M :1004-1023, M+M :944-963)
+__device__ __forceinline__ M12 blend2(const M12 &a, const M12 &b, float s1, float l) {
+    M12 r;
+    r.p0 = a.p0 * s1 + b.p0 * l; r.p1 = a.p1 * s1 + b.p1 * l;
+    r.p2 = a.p2 * s1 + b.p2 * l; r.p3 = a.p3 * s1 + b.p3 * l;
+    r.q0 = a.q0 * s1 + b.q0 * l; r.q1 = a.q1 * s1 + b.q1 * l;
     return r;
 }
-__device__ __forceinline__ float4 blend4_col(const float4 m0, const float4 m1, const float4 m2,
-                                             const float4 m3, float w0, float w1, float w2,
-                                             float w3) {
-    // ((m0*w0 + m1*w1) + m2*w2) + m3*w3 per element (poser_impl.inl:433; no normalisation)
-    float4 r;
-    r.x = ((m0.x * w0 + m1.x * w1) + m2.x * w2) + m3.x * w3;
-    r.y = ((m0.y * w0 + m1.y * w1) + m2.y * w2) + m3.y * w3;
-    r.z = ((m0.z * w0 + m1.z * w1) + m2.z * w2) + m3.z * w3;
-    r.w = ((m0.w * w0 + m1.w * w1) + m2.w * w2) + m3.w * w3;
+// ((m0*w0 + m1*w1) + m2*w2) + m3*w3 per element (poser_impl.inl:433; weights not normalised)
+__device__ __forceinline__ v2f blend4_pair(v2f a, v2f b, v2f c, v2f d, float w0, float w1, float w2,
+                                           float w3) {
+    return ((a * w0 + b * w1) + c * w2) + d * w3;
+}
+__device__ __forceinline__ M12 blend4(const M12 &a, const M12 &b, const M12 &c, const M12 &d,
+                                      float w0, float w1, float w2, float w3) {
+    M12 r;
+    r.p0 = blend4_pair(a.p0, b.p0, c.p0, d.p0, w0, w1, w2, w3);
+    r.p1 = blend4_pair(a.p1, b.p1, c.p1, d.p1, w0, w1, w2, w3);
+    r.p2 = blend4_pair(a.p2, b.p2, c.p2, d.p2, w0, w1, w2, w3);
+    r.p3 = blend4_pair(a.p3, b.p3, c.p3, d.p3, w0, w1, w2, w3);
+    r.q0 = blend4_pair(a.q0, b.q0, c.q0, d.q0, w0, w1, w2, w3);
+    r.q1 = blend4_pair(a.q1, b.q1, c.q1, d.q1, w0, w1, w2, w3);
     return r;
 }
-__device__ __forceinline__ float xform_pos(const float4 c, float x, float y, float z) {
-    return ((x * c.x + y * c.y) + z * c.z) + c.w;  // transform(), math_impl.inl:1039-1045
+// transform(): out[j] = ((x*m0j + y*m1j) + z*m2j) + m3j   (math_impl.inl:1039-1045)
+__device__ __forceinline__ void xform_pos(const M12 &m, v2f xy, float z, v2f &oxy, float &oz) {
+    oxy = ((m.p0 * xy.x + m.p1 * xy.y) + m.p2 * z) + m.p3;
+    const v2f t = m.q0 * xy;
+    oz = ((t.x + t.y) + z * m.q1.x) + m.q1.y;
 }
-__device__ __forceinline__ float xform_nrm(const float4 c, float x, float y, float z) {
-    return (x * c.x + y * c.y) + z * c.z;          // rotate(), math_impl.inl:1032-1038
+// rotate(): out[j] = (x*m0j + y*m1j) + z*m2j   (math_impl.inl:1032-1038) -- same matrix, no
+// inverse transpose, no renormalisation
+__device__ __forceinline__ void xform_nrm(const M12 &m, v2f xy, float z, v2f &oxy, float &oz) {
+    oxy = (m.p0 * xy.x + m.p1 * xy.y) + m.p2 * z;
+    const v2f t = m.q0 * xy;
+    oz = (t.x + t.y) + z * m.q1.x;
 }
 
-// ---- cooperative copy of one LDS image to global, 16-byte stores where whole chunks fit ----------
-// The image mirrors global memory from the 16-byte boundary below element `base`:
+// ---- cooperative copy of LDS images to global, 16-byte stores where whole chunks fit -------------
+// An image mirrors global memory from the 16-byte boundary below element `base`:
 // LDS element (shift + i) <-> out[base + i], shift = base % (16/sizeof(T)).
 template <typename T>
-__device__ __forceinline__ void copy_out_image(const unsigned char *img, T *out, size_t base,
-                                               uint32_t shift, uint32_t n, bool aligned16,
-                                               int tid) {
+__device__ __forceinline__ void copy_chunk(const unsigned char *img, T *g, uint32_t q, uint32_t shift,
+                                           uint32_t n, bool aligned16, bool no_store) {
     constexpr uint32_t EPC = 16 / sizeof(T);
-    const uint32_t nchunks = (shift + n + EPC - 1) / EPC;
-    T *g = out + base - shift;
-    const T *l = reinterpret_cast<const T *>(img);
-    for (uint32_t q = tid; q < nchunks; q += kThreads) {
-        const uint32_t lo = q * EPC;
-        if (aligned16 && lo >= shift && lo + EPC <= shift + n) {
-            const float4 v = *reinterpret_cast<const float4 *>(img + size_t(q) * 16);
-            *reinterpret_cast<float4 *>(g + lo) = v;
-        } else {
+    const uint32_t lo = q * EPC;
+    if (aligned16 && lo >= shift && lo + EPC <= shift + n) {
+        const float4 v = *reinterpret_cast<const float4 *>(img + size_t(q) * 16);
+#ifdef MMDX_ABLATE
+        if (no_store) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
+#endif
+        *reinterpret_cast<float4 *>(g + lo) = v;
+    } else {
+        const T *l = reinterpret_cast<const T *>(img);
 #pragma unroll
-            for (uint32_t e = 0; e < EPC; ++e) {
-                const uint32_t i = lo + e;
-                if (i >= shift && i < shift + n) g[i] = l[i];
-            }
+        for (uint32_t e = 0; e < EPC; ++e) {
+            const uint32_t i = lo + e;
+            if (i >= shift && i < shift + n) g[i] = l[i];
         }
     }
 }
 
+// two images (A then B) in one pass over the workgroup's threads
+template <int THREADS, typename TA, typename TB>
+__device__ __forceinline__ void copy_out2(const unsigned char *imgA, TA *outA, size_t baseA,
+                                          uint32_t shA, uint32_t nA, const unsigned char *imgB,
+                                          TB *outB, size_t baseB, uint32_t shB, uint32_t nB,
+                                          bool aligned16, int tid, bool no_store) {
+    const uint32_t ncA = (shA + nA + 16 / sizeof(TA) - 1) / (16 / sizeof(TA));
+    const uint32_t ncB = (shB + nB + 16 / sizeof(TB) - 1) / (16 / sizeof(TB));
+    TA *gA = outA + baseA - shA;
+    TB *gB = outB + baseB - shB;
+    for (uint32_t q = tid; q < ncA + ncB; q += THREADS) {
+        if (q < ncA) copy_chunk<TA>(imgA, gA, q, shA, nA, aligned16, no_store);
+        else copy_chunk<TB>(imgB, gB, q - ncA, shB, nB, aligned16, no_store);
+    }
+}
+
+
+// Fast path for a FULL tile whose output range starts on a 16-byte boundary (every tile but the last
+// when NV % 4 == 0): all LDS reads are issued first, then all stores -- one LDS round trip per
+// instance instead of one per chunk, no per-chunk branching.  CA / CB = 16-byte chunks of image A / B;
+// image B sits `gapB` bytes after image A in LDS.
+template <int THREADS, int CA, int CB, int I>
+struct CopyFast {
+    // step I of ceil((CA+CB)/THREADS): load chunk q = tid + I*THREADS, recurse (so every LDS read is
+    // issued before the first store), then store it.  Scalars only -- an indexed float4 array here
+    // ends up in scratch memory with a vmcnt(0) in front of every store.
+    static __device__ __forceinline__ void run(const unsigned char *img, uint32_t gapB, float4 *outA,
+                                               float4 *outB, int tid, bool no_store) {
+        constexpr int TOTAL = CA + CB;
+        if constexpr (I * THREADS < TOTAL) {
+            constexpr bool full = (I + 1) * THREADS <= TOTAL;
+            const int q = tid + I * THREADS;
+            const bool inA = (I + 1) * THREADS <= CA ? true : (I * THREADS >= CA ? false : q < CA);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (full || q < TOTAL)
+                v = *reinterpret_cast<const float4 *>(img + (inA ? 0u : gapB - uint32_t(CA) * 16u) +
+                                                      size_t(q) * 16);
+            CopyFast<THREADS, CA, CB, I + 1>::run(img, gapB, outA, outB, tid, no_store);
+#ifdef MMDX_ABLATE
+            if (no_store) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
+#endif
+            if (full || q < TOTAL) {
+                float4 *dst = inA ? outA + q : outB + (q - CA);
+                *dst = v;
+            }
+        }
+    }
+};
+template <int THREADS, int CA, int CB>
+__device__ __forceinline__ void copy_out_fast(const unsigned char *img, uint32_t gapB, float4 *outA,
+                                              float4 *outB, int tid, bool no_store) {
+    CopyFast<THREADS, CA, CB, 0>::run(img, gapB, outA, outB, tid, no_store);
+}
+
 struct Slot {
-    float px, py, pz, nx, ny, nz, u, v;
+    v2f pxy, nxy, uv;
+    float pz, nz;
     float w0, w1, w2, w3;
-    uint32_t b0, b1, b2, b3;  // float4 index of the bone's first column inside one instance's palette
+    uint32_t b0, b1, b2, b3;  // float4 index of the bone's entry inside one instance's palette
     uint32_t perm;
     uint32_t rb, re;          // CSR row [rb, re)
     int cls;
@@ -116,24 +199,26 @@ struct Slot {
 };
 
 template <bool F16>
-__device__ __forceinline__ void load_entry(const void *entries, uint32_t e, float &ox, float &oy,
-                                           float &oz, uint32_t &slot) {
+__device__ __forceinline__ void load_entry(const void *entries, uint32_t e, v2f &oxy, float &oz,
+                                           uint32_t &slot) {
     if constexpr (F16) {
         const uint2 r = reinterpret_cast<const uint2 *>(entries)[e];
-        ox = h2f(r.x & 0xffffu);
-        oy = h2f(r.x >> 16);
+        oxy = v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)};
         oz = h2f(r.y & 0xffffu);
         slot = r.y >> 16;
     } else {
         const float4 r = reinterpret_cast<const float4 *>(entries)[e];
-        ox = r.x; oy = r.y; oz = r.z;
+        oxy = v2f{r.x, r.y};
+        oz = r.z;
         slot = __float_as_uint(r.w);
     }
 }
 
 // ---- the deformation kernel ----------------------------------------------------------------------
-template <int LAYOUT, int MORPH, bool F16>
-__global__ __launch_bounds__(kThreads) void deform_kernel(const DeformParams p) {
+// THREADS = 512: one sorted slot per lane, 8 waves per workgroup; THREADS = 256: two slots per lane.
+template <int THREADS, int LAYOUT, int MORPH, bool F16>
+__global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
+    constexpr int VPT = int(kTileVerts) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const TileHdr &th = p.tiles[blockIdx.x];
@@ -144,56 +229,63 @@ __global__ __launch_bounds__(kThreads) void deform_kernel(const DeformParams p) 
     unsigned char *stage = smem + p.stage_off;
     constexpr uint32_t kStage = stage_bytes(LAYOUT);
 
-    // 1. bone palettes of the group's instances -> LDS (only the tile's bones, transposed columns)
-    for (uint32_t idx = tid; idx < gcount * nbt; idx += kThreads) {
+    // 1. bone palettes of the group's instances -> LDS: only the tile's bones, in the pair layout
+#ifdef MMDX_ABLATE
+    if (!(p.ablate & 32u))
+#endif
+    for (uint32_t idx = tid; idx < gcount * nbt; idx += THREADS) {
         const uint32_t g = idx / nbt, lb = idx - g * nbt;
         const uint32_t bone = p.bone_list[th.bone_off + lb];
         const float4 *src =
             reinterpret_cast<const float4 *>(p.palettes + (size_t(inst0 + g) * p.nb + bone) * 16);
         const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
         float4 *dst = pal + size_t(g) * p.pal_stride + lb * 3;
-        dst[0] = make_float4(r0.x, r1.x, r2.x, r3.x);
-        dst[1] = make_float4(r0.y, r1.y, r2.y, r3.y);
+        dst[0] = make_float4(r0.x, r0.y, r1.x, r1.y);
+        dst[1] = make_float4(r2.x, r2.y, r3.x, r3.y);
         dst[2] = make_float4(r0.z, r1.z, r2.z, r3.z);
     }
     // 2. morph slot weights of the group -> LDS
     if constexpr (MORPH == kMorphFused1) {
         float *wl = reinterpret_cast<float *>(smem + p.w_off);
-        for (uint32_t s = tid; s < p.ns; s += kThreads) wl[s] = p.wslot[size_t(inst0) * p.ns + s];
+        for (uint32_t s = tid; s < p.ns; s += THREADS) wl[s] = p.wslot[size_t(inst0) * p.ns + s];
     } else if constexpr (MORPH == kMorphFused4) {
         float4 *wl4 = reinterpret_cast<float4 *>(smem + p.w_off);
         const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t(inst0 / 4) * p.ns;
         const uint32_t n = ((gcount + 3) / 4) * p.ns;
-        for (uint32_t i = tid; i < n; i += kThreads) wl4[i] = src[i];
+        for (uint32_t i = tid; i < n; i += THREADS) wl4[i] = src[i];
     }
 
-    // 3. static per-vertex data -> registers (sorted slot s = tid + k*256)
-    Slot sl[kVPT];
+    // 3. static per-vertex data -> registers (sorted slot s = tid + k*THREADS)
+    Slot sl[VPT];
 #pragma unroll
-    for (int k = 0; k < kVPT; ++k) {
+    for (int k = 0; k < VPT; ++k) {
         Slot &q = sl[k];
-        const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
+        const uint32_t s = uint32_t(tid) + uint32_t(k) * THREADS;
         q.act = s < nvt;
         q.cls = s < n1 ? 0 : (s < n12 ? 1 : 2);
-        q.px = q.py = q.pz = q.nx = q.ny = q.nz = q.u = q.v = 0.f;
+        q.pxy = q.nxy = q.uv = v2f{0.f, 0.f};
+        q.pz = q.nz = 0.f;
         q.w0 = q.w1 = q.w2 = q.w3 = 0.f;
         q.b0 = q.b1 = q.b2 = q.b3 = 0;
         q.perm = 0; q.rb = q.re = 0;
+#ifdef MMDX_ABLATE
+        if (p.ablate & 64u) { q.perm = s; continue; }
+#endif
         if (q.act) {
             const size_t gs = size_t(v0) + s;
             if constexpr (MORPH == kMorphShared) {
-                q.px = p.morphed[gs * 3]; q.py = p.morphed[gs * 3 + 1]; q.pz = p.morphed[gs * 3 + 2];
+                q.pxy = v2f{p.morphed[gs * 3], p.morphed[gs * 3 + 1]}; q.pz = p.morphed[gs * 3 + 2];
             } else if constexpr (F16) {
                 const uint2 r = reinterpret_cast<const uint2 *>(p.spos)[gs];
-                q.px = h2f(r.x & 0xffffu); q.py = h2f(r.x >> 16); q.pz = h2f(r.y & 0xffffu);
+                q.pxy = v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)}; q.pz = h2f(r.y & 0xffffu);
             } else {
                 const float *sp = reinterpret_cast<const float *>(p.spos) + gs * 3;
-                q.px = sp[0]; q.py = sp[1]; q.pz = sp[2];
+                q.pxy = v2f{sp[0], sp[1]}; q.pz = sp[2];
             }
-            q.nx = p.snrm[gs * 3]; q.ny = p.snrm[gs * 3 + 1]; q.nz = p.snrm[gs * 3 + 2];
+            q.nxy = v2f{p.snrm[gs * 3], p.snrm[gs * 3 + 1]}; q.nz = p.snrm[gs * 3 + 2];
             if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
                 const float2 uv = reinterpret_cast<const float2 *>(p.suv)[gs];
-                q.u = uv.x; q.v = uv.y;
+                q.uv = v2f{uv.x, uv.y};
             }
             q.perm = p.perm[gs];
             if constexpr (MORPH == kMorphFused1 || MORPH == kMorphFused4) {
@@ -220,8 +312,7 @@ __global__ __launch_bounds__(kThreads) void deform_kernel(const DeformParams p) 
 
     uint32_t buf = 0;
     // one instance: skin the thread's slots, scatter to the LDS image, write the image out
-    auto run_instance = [&](uint32_t g, const float (&cx)[kVPT], const float (&cy)[kVPT],
-                            const float (&cz)[kVPT]) {
+    auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT]) {
         const float4 *P = pal + size_t(g) * p.pal_stride;
         unsigned char *img = stage + buf * kStage;
         const size_t vbase = size_t(inst0 + g) * p.nv + v0;  // first output vertex of this tile
@@ -229,68 +320,103 @@ __global__ __launch_bounds__(kThreads) void deform_kernel(const DeformParams p) 
         const uint32_t sh4 = al ? uint32_t((vbase * 3) & 3) : 0u;
         const uint32_t sh8 = al ? uint32_t((vbase * 3) & 7) : 0u;
 #pragma unroll
-        for (int k = 0; k < kVPT; ++k) {
+        for (int k = 0; k < VPT; ++k) {
             const Slot &q = sl[k];
             if (!q.act) continue;
-            float4 c0, c1, c2;
+            M12 m;
+#ifdef MMDX_ABLATE
+            if (p.ablate & 16u) continue;   // stores only: no palette reads, math or image writes
+            if (p.ablate & 2u) {
+                m.p0 = v2f{1.f, 0.f}; m.p1 = v2f{0.f, 1.f}; m.p2 = v2f{0.f, 0.f}; m.p3 = v2f{0.f, 0.f};
+                m.q0 = v2f{0.f, 0.f}; m.q1 = v2f{1.f, 0.f};
+            } else
+#endif
             if (q.cls == 0) {
-                c0 = P[q.b0]; c1 = P[q.b0 + 1]; c2 = P[q.b0 + 2];
+                m = load_m12(P, q.b0);
             } else if (q.cls == 1) {
                 // Lerp(S[b1], S[b0])[w]  (poser_impl.inl:420-422, math_impl.inl:1246-1254)
-                const float4 a0 = P[q.b1], a1 = P[q.b1 + 1], a2 = P[q.b1 + 2];
-                const float4 e0 = P[q.b0], e1 = P[q.b0 + 1], e2 = P[q.b0 + 2];
-                const float l = q.w0, s1 = 1.0f - l;
-                c0 = blend2_col(a0, e0, s1, l);
-                c1 = blend2_col(a1, e1, s1, l);
-                c2 = blend2_col(a2, e2, s1, l);
-                if (l < kLerpLo) { c0 = a0; c1 = a1; c2 = a2; }
-                else if (l > kLerpHi) { c0 = e0; c1 = e1; c2 = e2; }
+                const M12 a = load_m12(P, q.b1), e = load_m12(P, q.b0);
+                const float l = q.w0;
+                m = blend2(a, e, 1.0f - l, l);
+                // epsilon short-circuits: rare, so only waves that hold such a weight pay for them
+                const bool lo = l < kLerpLo, hi = l > kLerpHi;
+                if (__builtin_amdgcn_ballot_w64(lo || hi) != 0) {
+                    if (lo) m = a;
+                    else if (hi) m = e;
+                }
             } else {
-                const float4 m00 = P[q.b0], m01 = P[q.b0 + 1], m02 = P[q.b0 + 2];
-                const float4 m10 = P[q.b1], m11 = P[q.b1 + 1], m12 = P[q.b1 + 2];
-                const float4 m20 = P[q.b2], m21 = P[q.b2 + 1], m22 = P[q.b2 + 2];
-                const float4 m30 = P[q.b3], m31 = P[q.b3 + 1], m32 = P[q.b3 + 2];
-                c0 = blend4_col(m00, m10, m20, m30, q.w0, q.w1, q.w2, q.w3);
-                c1 = blend4_col(m01, m11, m21, m31, q.w0, q.w1, q.w2, q.w3);
-                c2 = blend4_col(m02, m12, m22, m32, q.w0, q.w1, q.w2, q.w3);
+                const M12 a = load_m12(P, q.b0), b = load_m12(P, q.b1), c = load_m12(P, q.b2),
+                          d = load_m12(P, q.b3);
+                m = blend4(a, b, c, d, q.w0, q.w1, q.w2, q.w3);
             }
+            v2f oxy, rxy;
+            float oz, rz;
+            xform_pos(m, cxy[k], cz[k], oxy, oz);
+            xform_nrm(m, q.nxy, q.nz, rxy, rz);
             // pos_scale is a separate multiply after the transform (main.cpp:848-850); x*1.0f == x
-            const float ox = xform_pos(c0, cx[k], cy[k], cz[k]) * p.pos_scale;
-            const float oy = xform_pos(c1, cx[k], cy[k], cz[k]) * p.pos_scale;
-            const float oz = xform_pos(c2, cx[k], cy[k], cz[k]) * p.pos_scale;
-            const float rx = xform_nrm(c0, q.nx, q.ny, q.nz);
-            const float ry = xform_nrm(c1, q.nx, q.ny, q.nz);
-            const float rz = xform_nrm(c2, q.nx, q.ny, q.nz);
+            oxy = oxy * p.pos_scale;
+            oz = oz * p.pos_scale;
+#ifdef MMDX_ABLATE
+            if (p.ablate & 4u) {
+                asm volatile("" ::"v"(oxy.x), "v"(oxy.y), "v"(oz), "v"(rxy.x), "v"(rxy.y), "v"(rz));
+                continue;
+            }
+#endif
             if constexpr (LAYOUT == MMDX_OUT_SOA) {
                 float *A = reinterpret_cast<float *>(img) + sh4 + q.perm * 3;
                 float *B = reinterpret_cast<float *>(img + kSoaImgBytes) + sh4 + q.perm * 3;
-                A[0] = ox; A[1] = oy; A[2] = oz;
-                B[0] = rx; B[1] = ry; B[2] = rz;
+                A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
+                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
             } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
                 float4 *I = reinterpret_cast<float4 *>(img) + q.perm * 2;
-                I[0] = make_float4(ox, oy, oz, rx);
-                I[1] = make_float4(ry, rz, q.u, q.v);
+                I[0] = make_float4(oxy.x, oxy.y, oz, rxy.x);
+                I[1] = make_float4(rxy.y, rz, q.uv.x, q.uv.y);
             } else {
                 unsigned short *A = reinterpret_cast<unsigned short *>(img) + sh8 + q.perm * 3;
                 float *B = reinterpret_cast<float *>(img + kP16ImgBytes) + sh4 + q.perm * 3;
-                A[0] = f2h(ox); A[1] = f2h(oy); A[2] = f2h(oz);
-                B[0] = rx; B[1] = ry; B[2] = rz;
+                A[0] = f2h(oxy.x); A[1] = f2h(oxy.y); A[2] = f2h(oz);
+                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
             }
         }
+#ifdef MMDX_ABLATE
+        if (p.ablate & 4u) return;
+        const bool ns = (p.ablate & 1u) != 0;
+#else
+        constexpr bool ns = false;
+#endif
+#ifdef MMDX_ABLATE
+        if (!(p.ablate & 8u))
+#endif
         __syncthreads();
+        const bool fast = al && nvt == kTileVerts && sh4 == 0 && sh8 == 0;
         if constexpr (LAYOUT == MMDX_OUT_SOA) {
-            copy_out_image<float>(img, reinterpret_cast<float *>(p.out_a), vbase * 3, sh4, nvt * 3,
-                                  al, tid);
-            copy_out_image<float>(img + kSoaImgBytes, reinterpret_cast<float *>(p.out_b), vbase * 3,
-                                  sh4, nvt * 3, al, tid);
+            float *oa = reinterpret_cast<float *>(p.out_a), *ob = reinterpret_cast<float *>(p.out_b);
+            if (fast)
+                copy_out_fast<THREADS, kTileVerts * 12 / 16, kTileVerts * 12 / 16>(
+                    img, kSoaImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
+                    reinterpret_cast<float4 *>(ob + vbase * 3), tid, ns);
+            else
+                copy_out2<THREADS, float, float>(img, oa, vbase * 3, sh4, nvt * 3, img + kSoaImgBytes, ob,
+                                                 vbase * 3, sh4, nvt * 3, al, tid, ns);
         } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
-            copy_out_image<float>(img, reinterpret_cast<float *>(p.out_a), vbase * 8, 0u, nvt * 8,
-                                  al, tid);
+            float *oa = reinterpret_cast<float *>(p.out_a);
+            if (fast)
+                copy_out_fast<THREADS, kTileVerts * 32 / 16, 0>(
+                    img, 0u, reinterpret_cast<float4 *>(oa + vbase * 8), nullptr, tid, ns);
+            else
+                copy_out2<THREADS, float, float>(img, oa, vbase * 8, 0u, nvt * 8, img, oa, 0, 0u, 0u, al,
+                                                 tid, ns);
         } else {
-            copy_out_image<unsigned short>(img, reinterpret_cast<unsigned short *>(p.out_a),
-                                           vbase * 3, sh8, nvt * 3, al, tid);
-            copy_out_image<float>(img + kP16ImgBytes, reinterpret_cast<float *>(p.out_b), vbase * 3,
-                                  sh4, nvt * 3, al, tid);
+            unsigned short *oa = reinterpret_cast<unsigned short *>(p.out_a);
+            float *ob = reinterpret_cast<float *>(p.out_b);
+            if (fast)
+                copy_out_fast<THREADS, kTileVerts * 6 / 16, kTileVerts * 12 / 16>(
+                    img, kP16ImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
+                    reinterpret_cast<float4 *>(ob + vbase * 3), tid, ns);
+            else
+                copy_out2<THREADS, unsigned short, float>(img, oa, vbase * 3, sh8, nvt * 3,
+                                                          img + kP16ImgBytes, ob, vbase * 3, sh4, nvt * 3,
+                                                          al, tid, ns);
         }
         buf ^= 1u;  // double-buffered image: the next instance writes the other one, so one barrier
                     // per instance is enough
@@ -298,55 +424,60 @@ __global__ __launch_bounds__(kThreads) void deform_kernel(const DeformParams p) 
 
     // 4. the group's instances
     if constexpr (MORPH == kMorphNone || MORPH == kMorphShared) {
-        float cx[kVPT], cy[kVPT], cz[kVPT];
+        v2f cxy[VPT];
+        float cz[VPT];
 #pragma unroll
-        for (int k = 0; k < kVPT; ++k) { cx[k] = sl[k].px; cy[k] = sl[k].py; cz[k] = sl[k].pz; }
-        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cx, cy, cz);
+        for (int k = 0; k < VPT; ++k) { cxy[k] = sl[k].pxy; cz[k] = sl[k].pz; }
+        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cxy, cz);
     } else if constexpr (MORPH == kMorphFused1) {
         // vertex_image = 0; for each applied entry: image = image + offset*rate
         // (poser_impl.inl:340-346); coordinate = base + image (:407)
         const float *wl = reinterpret_cast<const float *>(smem + p.w_off);
-        float cx[kVPT], cy[kVPT], cz[kVPT];
+        v2f cxy[VPT];
+        float cz[VPT];
 #pragma unroll
-        for (int k = 0; k < kVPT; ++k) {
-            float dx = 0.f, dy = 0.f, dz = 0.f;
+        for (int k = 0; k < VPT; ++k) {
+            v2f dxy = v2f{0.f, 0.f};
+            float dz = 0.f;
             for (uint32_t e = sl[k].rb; e < sl[k].re; ++e) {
-                float ox, oy, oz; uint32_t slot;
-                load_entry<F16>(p.entries, e, ox, oy, oz, slot);
+                v2f oxy; float oz; uint32_t slot;
+                load_entry<F16>(p.entries, e, oxy, oz, slot);
                 const float w = wl[slot];
-                if (!(w < kMorphEps)) { dx = dx + ox * w; dy = dy + oy * w; dz = dz + oz * w; }
+                if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
             }
-            cx[k] = sl[k].px + dx; cy[k] = sl[k].py + dy; cz[k] = sl[k].pz + dz;
+            cxy[k] = sl[k].pxy + dxy; cz[k] = sl[k].pz + dz;
         }
-        run_instance(0, cx, cy, cz);
+        run_instance(0, cxy, cz);
     } else {
         const float4 *wl4 = reinterpret_cast<const float4 *>(smem + p.w_off);
         for (uint32_t g0 = 0; g0 < gcount; g0 += 4) {
-            float dx[kVPT][4], dy[kVPT][4], dz[kVPT][4];
+            v2f dxy[VPT][4];
+            float dz[VPT][4];
             const float4 *wq = wl4 + size_t(g0 / 4) * p.ns;
 #pragma unroll
-            for (int k = 0; k < kVPT; ++k) {
+            for (int k = 0; k < VPT; ++k) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dx[k][j] = 0.f; dy[k][j] = 0.f; dz[k][j] = 0.f; }
+                for (int j = 0; j < 4; ++j) { dxy[k][j] = v2f{0.f, 0.f}; dz[k][j] = 0.f; }
                 for (uint32_t e = sl[k].rb; e < sl[k].re; ++e) {
-                    float ox, oy, oz; uint32_t slot;
-                    load_entry<F16>(p.entries, e, ox, oy, oz, slot);
+                    v2f oxy; float oz; uint32_t slot;
+                    load_entry<F16>(p.entries, e, oxy, oz, slot);
                     const float4 w = wq[slot];
-                    if (!(w.x < kMorphEps)) { dx[k][0] += ox * w.x; dy[k][0] += oy * w.x; dz[k][0] += oz * w.x; }
-                    if (!(w.y < kMorphEps)) { dx[k][1] += ox * w.y; dy[k][1] += oy * w.y; dz[k][1] += oz * w.y; }
-                    if (!(w.z < kMorphEps)) { dx[k][2] += ox * w.z; dy[k][2] += oy * w.z; dz[k][2] += oz * w.z; }
-                    if (!(w.w < kMorphEps)) { dx[k][3] += ox * w.w; dy[k][3] += oy * w.w; dz[k][3] += oz * w.w; }
+                    if (!(w.x < kMorphEps)) { dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x; }
+                    if (!(w.y < kMorphEps)) { dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y; }
+                    if (!(w.z < kMorphEps)) { dxy[k][2] += oxy * w.z; dz[k][2] += oz * w.z; }
+                    if (!(w.w < kMorphEps)) { dxy[k][3] += oxy * w.w; dz[k][3] += oz * w.w; }
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (g0 + j < gcount) {
-                    float cx[kVPT], cy[kVPT], cz[kVPT];
+                    v2f cxy[VPT];
+                    float cz[VPT];
 #pragma unroll
-                    for (int k = 0; k < kVPT; ++k) {
-                        cx[k] = sl[k].px + dx[k][j]; cy[k] = sl[k].py + dy[k][j]; cz[k] = sl[k].pz + dz[k][j];
+                    for (int k = 0; k < VPT; ++k) {
+                        cxy[k] = sl[k].pxy + dxy[k][j]; cz[k] = sl[k].pz + dz[k][j];
                     }
-                    run_instance(g0 + j, cx, cy, cz);
+                    run_instance(g0 + j, cxy, cz);
                 }
             }
         }
@@ -366,16 +497,17 @@ __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParam
         const float *sp = reinterpret_cast<const float *>(p.spos) + gs * 3;
         bx = sp[0]; by = sp[1]; bz = sp[2];
     }
-    float dx = 0.f, dy = 0.f, dz = 0.f;
+    v2f dxy = v2f{0.f, 0.f};
+    float dz = 0.f;
     const uint32_t rb = p.row_ptr[gs], re = p.row_ptr[gs + 1];
     for (uint32_t e = rb; e < re; ++e) {
-        float ox, oy, oz; uint32_t slot;
-        load_entry<F16>(p.entries, e, ox, oy, oz, slot);
+        v2f oxy; float oz; uint32_t slot;
+        load_entry<F16>(p.entries, e, oxy, oz, slot);
         const float w = p.wslot[slot];
-        if (!(w < kMorphEps)) { dx = dx + ox * w; dy = dy + oy * w; dz = dz + oz * w; }
+        if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
     }
-    p.morphed[gs * 3] = bx + dx;
-    p.morphed[gs * 3 + 1] = by + dy;
+    p.morphed[gs * 3] = bx + dxy.x;
+    p.morphed[gs * 3 + 1] = by + dxy.y;
     p.morphed[gs * 3 + 2] = bz + dz;
 }
 
@@ -412,21 +544,29 @@ __global__ __launch_bounds__(kThreads) void fill_kernel(float4 *dst, size_t n) {
 
 using KernelFn = void (*)(const DeformParams);
 
-template <int LAYOUT, bool F16>
+template <int THREADS, int LAYOUT, bool F16>
 KernelFn pick_morph(int morph) {
     switch (morph) {
-    case kMorphNone: return deform_kernel<LAYOUT, kMorphNone, F16>;
-    case kMorphShared: return deform_kernel<LAYOUT, kMorphShared, F16>;
-    case kMorphFused1: return deform_kernel<LAYOUT, kMorphFused1, F16>;
-    default: return deform_kernel<LAYOUT, kMorphFused4, F16>;
+    case kMorphNone: return deform_kernel<THREADS, LAYOUT, kMorphNone, F16>;
+    case kMorphShared: return deform_kernel<THREADS, LAYOUT, kMorphShared, F16>;
+    case kMorphFused1: return deform_kernel<THREADS, LAYOUT, kMorphFused1, F16>;
+    default: return deform_kernel<THREADS, LAYOUT, kMorphFused4, F16>;
     }
 }
 
-KernelFn pick(int layout, int morph, bool f16) {
-    if (f16) return layout == MMDX_OUT_SOA_POS16 ? pick_morph<MMDX_OUT_SOA_POS16, true>(morph) : nullptr;
-    if (layout == MMDX_OUT_SOA) return pick_morph<MMDX_OUT_SOA, false>(morph);
-    if (layout == MMDX_OUT_VERTEX32) return pick_morph<MMDX_OUT_VERTEX32, false>(morph);
+template <int THREADS>
+KernelFn pick_t(int layout, int morph, bool f16) {
+    if (f16) return layout == MMDX_OUT_SOA_POS16 ? pick_morph<THREADS, MMDX_OUT_SOA_POS16, true>(morph) : nullptr;
+    if (layout == MMDX_OUT_SOA) return pick_morph<THREADS, MMDX_OUT_SOA, false>(morph);
+    if (layout == MMDX_OUT_VERTEX32) return pick_morph<THREADS, MMDX_OUT_VERTEX32, false>(morph);
     return nullptr;
+}
+
+KernelFn pick(int threads, int layout, int morph, bool f16) {
+#if MMDX_TILE >= 512
+    if (threads != 256) return pick_t<512>(layout, morph, f16);
+#endif
+    return pick_t<256>(layout, morph, f16);
 }
 
 }  // namespace
@@ -443,10 +583,11 @@ size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile
 }
 
 hipError_t prepare_kernels() {
-    for (int f16 = 0; f16 < 2; ++f16)
+    for (int threads = 256; threads <= 512; threads += 256)
+      for (int f16 = 0; f16 < 2; ++f16)
         for (int layout = 0; layout < 3; ++layout)
             for (int morph = 0; morph < 4; ++morph) {
-                KernelFn fn = pick(layout, morph, f16 != 0);
+                KernelFn fn = pick(threads, layout, morph, f16 != 0);
                 if (!fn) continue;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -456,12 +597,12 @@ hipError_t prepare_kernels() {
     return hipSuccess;
 }
 
-hipError_t launch_deform(int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles,
-                         size_t lds_bytes, hipStream_t stream) {
-    KernelFn fn = pick(layout, morph, f16);
+hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
+                         uint32_t ntiles, size_t lds_bytes, hipStream_t stream) {
+    KernelFn fn = pick(threads, layout, morph, f16);
     if (!fn) return hipErrorInvalidValue;
     const dim3 grid(ntiles, (p.ni + p.group - 1) / p.group);
-    hipLaunchKernelGGL(fn, grid, dim3(kThreads), lds_bytes, stream, p);
+    hipLaunchKernelGGL(fn, grid, dim3((threads == 256 || kTileVerts < 512) ? 256 : 512), lds_bytes, stream, p);
     return hipGetLastError();
 }
 

@@ -48,6 +48,8 @@ struct DeformParams {
     uint32_t w_off;
     float pos_scale;
     uint32_t out_aligned;        // out_a and out_b are 16-byte aligned
+    uint32_t ablate;             // MMDX_ABLATE builds only (tools/): bit0 no global stores,
+                                 // bit1 no skinning math, bit2 no staging/copy-out at all
 };
 
 struct FlattenParams {
@@ -63,8 +65,8 @@ struct FlattenParams {
 size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
                         uint32_t *stage_off, uint32_t *w_off);
 
-hipError_t launch_deform(int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles,
-                         size_t lds_bytes, hipStream_t stream);
+hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
+                         uint32_t ntiles, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_morph_apply(bool f16, const DeformParams &p, hipStream_t stream);
 hipError_t launch_flatten(const FlattenParams &p, hipStream_t stream);
 hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream);

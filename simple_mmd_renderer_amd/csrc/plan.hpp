@@ -25,7 +25,10 @@
 
 namespace mmdx {
 
-constexpr uint32_t kTileVerts = 512;      // vertices per tile = per 256-thread workgroup (2 per lane)
+#ifndef MMDX_TILE
+#define MMDX_TILE 512
+#endif
+constexpr uint32_t kTileVerts = MMDX_TILE;  // vertices per tile = per workgroup
 constexpr uint32_t kMaxGroupDepth = 64;   // group-morph nesting limit (cycles are rejected)
 
 struct TileHdr {                          // 48 bytes, read through the scalar cache

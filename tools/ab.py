@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of deform-kernel variants in ONE process (cdna guide, rule 24):
+N configurations x R rounds, median and min of the HIP-event kernel time per configuration.
+
+    python tools/ab.py "MMDX_GROUP=16" "MMDX_GROUP=8 MMDX_THREADS=256" ...
+
+Each argument is a space-separated list of VAR=VALUE settings read by libmmdx at call time
+(MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET, and MMDX_ABLATE in ablation builds).
+Workload: BASELINE config 3 (1024 x 50k crowd, shared morphs), override with AB_WORKLOAD=v32.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
+from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
+
+KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_ABLATE")
+
+
+def main():
+    cfgs = [dict(kv.split("=") for kv in a.split()) if a.strip() else {} for a in sys.argv[1:]] or [{}]
+    rounds = int(os.environ.get("AB_ROUNDS", "7"))
+    iters = int(os.environ.get("AB_ITERS", "10"))
+    layout = api.OUT_VERTEX32 if os.environ.get("AB_WORKLOAD") == "v32" else api.OUT_SOA
+    model = synth.make_config("config3_crowd")
+    ni = 1024
+    pals = synth.make_palettes(model, (np.arange(ni) * 3) % 1801)
+    rates = synth.morph_weights(model.nm, 30)[0]
+    dm = DeformModel(model)
+    d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
+    sa, sb = dm.out_sizes(layout, ni)
+    d_a, d_b = DeviceBuffer(sa), (DeviceBuffer(sb) if sb else None)
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    dm.profile_enable(True)
+    res = [[] for _ in cfgs]
+    for r in range(rounds + 1):
+        for ci, cfg in enumerate(cfgs):
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(cfg)
+            t = []
+            for _ in range(iters):
+                dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout,
+                                      flags, 0.1 if layout == api.OUT_VERTEX32 else 1.0)
+                t.append(dm.profile_last()[0])
+            if r:                                   # round 0 = warm-up
+                res[ci].append(float(np.median(t)))
+    for cfg, r in zip(cfgs, res):
+        r = np.asarray(r) * 1e3
+        name = " ".join(f"{k}={v}" for k, v in cfg.items()) or "(defaults)"
+        print(f"{name:48s} median {np.median(r):7.1f} us   min {r.min():7.1f}   max {r.max():7.1f}")
+
+
+if __name__ == "__main__":
+    main()
