@@ -189,10 +189,13 @@ MMDX_API mmdx_status mmdx_sync(mmdx_model_t model);
 /* ---- timing on the handle's stream (HIP events; for bench harnesses) ------------------------- */
 MMDX_API mmdx_status mmdx_timer_start(mmdx_model_t model);
 MMDX_API mmdx_status mmdx_timer_stop(mmdx_model_t model, float *elapsed_ms); /* syncs the stream  */
-/* Milliseconds spent in the skinning kernel(s) / morph kernel(s) of the LAST mmdx_deform_batched
- * call, measured with HIP events around each launch when enabled (adds event overhead). */
+/* Per-kernel timing without perturbing the launch stream: while enabled, every mmdx_deform_batched
+ * call records HIP events around its morph kernels and around its skinning kernel (no host sync).
+ * mmdx_profile_collect waits for the recorded calls, returns how many there were and the summed
+ * milliseconds of the skinning kernel and of the morph pass, and resets the recording. */
 MMDX_API mmdx_status mmdx_profile_enable(mmdx_model_t model, int32_t enabled);
-MMDX_API mmdx_status mmdx_profile_last(mmdx_model_t model, float *skin_ms, float *morph_ms);
+MMDX_API mmdx_status mmdx_profile_collect(mmdx_model_t model, uint32_t *n_calls, float *skin_ms_total,
+                                          float *morph_ms_total);
 
 /* ---- plain device-memory helpers (thin hipMalloc / hipMemcpy wrappers) ----------------------- */
 /* So that C, C++ and ctypes callers can keep palettes and outputs resident in HBM without linking

@@ -80,7 +80,7 @@ SIGNATURES = {
     "mmdx_timer_start": (C.c_int32, [C.c_void_p]),
     "mmdx_timer_stop": (C.c_int32, [C.c_void_p, _f32p]),
     "mmdx_profile_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
-    "mmdx_profile_last": (C.c_int32, [C.c_void_p, _f32p, _f32p]),
+    "mmdx_profile_collect": (C.c_int32, [C.c_void_p, _u32p, _f32p, _f32p]),
     "mmdx_device_malloc": (C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
     "mmdx_device_free": (C.c_int32, [C.c_void_p]),
     "mmdx_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -79,9 +79,13 @@ struct mmdx_model_s {
     Plan plan;
     int device = -1;  // -1: host-only
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_m0 = nullptr,
-               ev_m1 = nullptr;
-    bool profile = false, prof_valid = false, prof_morph = false;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    // per-call kernel timing (mmdx_profile_*): event quadruples {skin0, skin1, morph0, morph1},
+    // recorded on the launch stream without any host sync; read back by mmdx_profile_collect
+    std::vector<hipEvent_t> prof_events;
+    std::vector<uint8_t> prof_has_morph;
+    size_t prof_calls = 0;
+    bool profile = false;
     uint64_t device_bytes = 0;
     // static streams
     DevBuf tiles, spos, snrm, suv, perm, skin1, skin2_ids, skin2_w, skin4_ids, skin4_w, bone_list,
@@ -91,6 +95,8 @@ struct mmdx_model_s {
 };
 
 namespace {
+
+constexpr size_t kMaxProfiledCalls = 1 << 16;
 
 int env_int(const char *name, int dflt) {
     const char *s = std::getenv(name);
@@ -131,8 +137,9 @@ void free_model(mmdx_model_s *m) {
                           &m->entries, &m->slot_top, &m->chain_off, &m->chain_rate, &m->pal, &m->rates,
                           &m->wslot, &m->morphed, &m->out_a, &m->out_b})
             b->release();
-        for (hipEvent_t ev : {m->ev_t0, m->ev_t1, m->ev_s0, m->ev_s1, m->ev_m0, m->ev_m1})
+        for (hipEvent_t ev : {m->ev_t0, m->ev_t1})
             if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : m->prof_events) (void)hipEventDestroy(ev);
         if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     }
     delete m;
@@ -223,7 +230,7 @@ mmdx_status mmdx_model_create(const mmdx_model_desc *desc, mmdx_model_t *out_mod
     if ((e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return bail(hip_fail(e, "hipStreamCreate"));
     m->stream = m->own_stream;
-    for (hipEvent_t *ev : {&m->ev_t0, &m->ev_t1, &m->ev_s0, &m->ev_s1, &m->ev_m0, &m->ev_m1})
+    for (hipEvent_t *ev : {&m->ev_t0, &m->ev_t1})
         if ((e = hipEventCreate(ev)) != hipSuccess) return bail(hip_fail(e, "hipEventCreate"));
     st = upload_model(m);
     if (st != MMDX_OK) return bail(st);
@@ -301,6 +308,17 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     const uint64_t nvi = uint64_t(ni) * p.nv;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = m->stream;
+    hipEvent_t *pev = nullptr;  // {skin0, skin1, morph0, morph1} of this call when profiling
+    if (m->profile) {
+        if (m->prof_calls >= kMaxProfiledCalls)
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_profile: too many calls without mmdx_profile_collect");
+        while (m->prof_events.size() < 4 * (m->prof_calls + 1)) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            m->prof_events.push_back(ev);
+        }
+        pev = m->prof_events.data() + 4 * m->prof_calls;
+    }
 
     DeformParams dp;
     std::memset(&dp, 0, sizeof(dp));
@@ -360,14 +378,13 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         const size_t rows = f.quad ? size_t((niw + 3) / 4) * 4 : niw;
         HIP_TRY(m->wslot.ensure(rows * p.ns * 4));
         f.out = static_cast<float *>(m->wslot.ptr);
-        if (m->profile) HIP_TRY(hipEventRecord(m->ev_m0, st));
+        if (pev) HIP_TRY(hipEventRecord(pev[2], st));
         HIP_TRY(launch_flatten(f, st));
         dp.wslot = f.out;
         dp.morphed = static_cast<float *>(m->morphed.ptr);
         if (morph == kMorphShared) HIP_TRY(launch_morph_apply(p.f16, dp, st));
-        if (m->profile) HIP_TRY(hipEventRecord(m->ev_m1, st));
+        if (pev) HIP_TRY(hipEventRecord(pev[3], st));
     }
-    m->prof_morph = m->profile && morph != kMorphNone;
 
     // ---- outputs ---------------------------------------------------------------------------------
     const size_t bytes_a = out_bytes_a(layout, nvi), bytes_b = out_bytes_b(layout, nvi);
@@ -385,7 +402,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     const uint32_t gmin = morph == kMorphFused4 ? 4u : 1u;
     uint32_t group = gmin;
     if (morph != kMorphFused1) {
-        const uint32_t target = uint32_t(env_int("MMDX_LDS_TARGET", 48 * 1024));
+        const uint32_t target = uint32_t(env_int("MMDX_LDS_TARGET", 42 * 1024));
         uint32_t so, wo;
         const size_t fixed = deform_lds_bytes(layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);
         const size_t per = size_t(p.max_tile_bones) * 48 + (morph == kMorphFused4 ? size_t(p.ns) * 4 : 0);
@@ -410,11 +427,13 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(lds) + " bytes of LDS (> 160 KiB): "
                                           "too many distinct bones in one vertex tile / too many morph slots");
 
-    if (m->profile) HIP_TRY(hipEventRecord(m->ev_s0, st));
-    HIP_TRY(launch_deform(env_int("MMDX_THREADS", 512), int(layout), morph, p.f16, dp, p.ntiles, lds, st));
-    if (m->profile) {
-        HIP_TRY(hipEventRecord(m->ev_s1, st));
-        m->prof_valid = true;
+    if (pev) HIP_TRY(hipEventRecord(pev[0], st));
+    HIP_TRY(launch_deform(env_int("MMDX_THREADS", 256), int(layout), morph, p.f16, dp, p.ntiles, lds, st));
+    if (pev) {
+        HIP_TRY(hipEventRecord(pev[1], st));
+        if (m->prof_has_morph.size() <= m->prof_calls) m->prof_has_morph.resize(m->prof_calls + 1);
+        m->prof_has_morph[m->prof_calls] = morph != kMorphNone;
+        ++m->prof_calls;
     }
 
     if (!out_dev) {
@@ -480,18 +499,30 @@ mmdx_status mmdx_timer_stop(mmdx_model_t m, float *ms) {
 mmdx_status mmdx_profile_enable(mmdx_model_t m, int32_t enabled) {
     if (!m || m->device < 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
     m->profile = enabled != 0;
-    m->prof_valid = false;
+    m->prof_calls = 0;
     return MMDX_OK;
 }
 
-mmdx_status mmdx_profile_last(mmdx_model_t m, float *skin_ms, float *morph_ms) {
-    if (!m || m->device < 0 || !skin_ms || !morph_ms)
+mmdx_status mmdx_profile_collect(mmdx_model_t m, uint32_t *n_calls, float *skin_ms_total,
+                                 float *morph_ms_total) {
+    if (!m || m->device < 0 || !n_calls || !skin_ms_total || !morph_ms_total)
         return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or host-only model");
-    if (!m->prof_valid) return fail(MMDX_ERR_INVALID_ARGUMENT, "no profiled call yet");
-    HIP_TRY(hipEventSynchronize(m->ev_s1));
-    HIP_TRY(hipEventElapsedTime(skin_ms, m->ev_s0, m->ev_s1));
-    *morph_ms = 0.f;
-    if (m->prof_morph) HIP_TRY(hipEventElapsedTime(morph_ms, m->ev_m0, m->ev_m1));
+    double skin = 0.0, morph = 0.0;
+    for (size_t c = 0; c < m->prof_calls; ++c) {
+        hipEvent_t *ev = m->prof_events.data() + 4 * c;
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        skin += ms;
+        if (m->prof_has_morph[c]) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
+            morph += ms;
+        }
+    }
+    *n_calls = uint32_t(m->prof_calls);
+    *skin_ms_total = float(skin);
+    *morph_ms_total = float(morph);
+    m->prof_calls = 0;
     return MMDX_OK;
 }
 

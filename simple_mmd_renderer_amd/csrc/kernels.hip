@@ -532,14 +532,16 @@ __global__ __launch_bounds__(kThreads) void flatten_kernel(const FlattenParams f
 }
 
 // ---- streaming copy / fill: the practical HBM ceiling printed next to the roofline ---------------
+// Every workgroup owns one contiguous 4 KiB chunk, workgroups in address order: the shape that
+// reached the highest store rate on MI355X in tools/bw_probe (a few-thousand-block grid-stride loop
+// is 30 % slower).
 __global__ __launch_bounds__(kThreads) void copy_kernel(float4 *dst, const float4 *src, size_t n) {
-    for (size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += size_t(gridDim.x) * kThreads)
-        dst[i] = src[i];
+    const size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 __global__ __launch_bounds__(kThreads) void fill_kernel(float4 *dst, size_t n) {
-    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
-    for (size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += size_t(gridDim.x) * kThreads)
-        dst[i] = v;
+    const size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < n) dst[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
 using KernelFn = void (*)(const DeformParams);
@@ -623,15 +625,15 @@ hipError_t launch_flatten(const FlattenParams &f, hipStream_t stream) {
 }
 
 hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(kThreads), 0, stream,
-                       reinterpret_cast<float4 *>(dst), reinterpret_cast<const float4 *>(src),
-                       bytes / 16);
+    hipLaunchKernelGGL(copy_kernel, dim3(uint32_t((bytes / 16 + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, stream, reinterpret_cast<float4 *>(dst),
+                       reinterpret_cast<const float4 *>(src), bytes / 16);
     return hipGetLastError();
 }
 
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(fill_kernel, dim3(256 * 8), dim3(kThreads), 0, stream,
-                       reinterpret_cast<float4 *>(dst), bytes / 16);
+    hipLaunchKernelGGL(fill_kernel, dim3(uint32_t((bytes / 16 + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, stream, reinterpret_cast<float4 *>(dst), bytes / 16);
     return hipGetLastError();
 }
 

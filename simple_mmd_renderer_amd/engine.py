@@ -248,10 +248,11 @@ class DeformModel:
     def profile_enable(self, on: bool) -> None:
         api.check(api.lib().mmdx_profile_enable(self.h, 1 if on else 0))
 
-    def profile_last(self) -> Tuple[float, float]:
-        s, m = C.c_float(0), C.c_float(0)
-        api.check(api.lib().mmdx_profile_last(self.h, C.byref(s), C.byref(m)))
-        return float(s.value), float(m.value)
+    def profile_collect(self) -> Tuple[int, float, float]:
+        """(calls, skin kernel ms total, morph pass ms total) since profile_enable / last collect."""
+        n, s, m = C.c_uint32(0), C.c_float(0), C.c_float(0)
+        api.check(api.lib().mmdx_profile_collect(self.h, C.byref(n), C.byref(s), C.byref(m)))
+        return int(n.value), float(s.value), float(m.value)
 
 
 class PoseImage:

@@ -42,13 +42,12 @@ def main():
             for k in KNOBS:
                 os.environ.pop(k, None)
             os.environ.update(cfg)
-            t = []
-            for _ in range(iters):
+            for _ in range(iters):                  # back-to-back, no host sync: sustained rate
                 dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout,
                                       flags, 0.1 if layout == api.OUT_VERTEX32 else 1.0)
-                t.append(dm.profile_last()[0])
+            n, skin, _ = dm.profile_collect()
             if r:                                   # round 0 = warm-up
-                res[ci].append(float(np.median(t)))
+                res[ci].append(skin / n)
     for cfg, r in zip(cfgs, res):
         r = np.asarray(r) * 1e3
         name = " ".join(f"{k}={v}" for k, v in cfg.items()) or "(defaults)"
