@@ -41,11 +41,6 @@ def algorithmic_bytes_config3(nv, nb, nm, ne, ni, n1, n2, n4):
     return deform, deform + morph
 
 
-def shard(total_instances: int, world: int, rank: int):
-    """Instance range of `rank`: [rank*NI/G, (rank+1)*NI/G)."""
-    return (rank * total_instances) // world, ((rank + 1) * total_instances) // world
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,42 +52,31 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-
-    # The product library first (it binds the HIP runtime at load), torch only for rendezvous.
+    # The product library first (it binds the HIP runtime at load); torch only for rendezvous.
     from simple_mmd_renderer_amd import _capi as api
     from simple_mmd_renderer_amd import build, synth
+    from simple_mmd_renderer_amd.crowd import Rendezvous, crowd_frames, shard_instances
     from simple_mmd_renderer_amd.engine import (DeformModel, DeviceBuffer, device_count, device_name,
                                                 device_select, device_synchronize)
     build.build()
     api.lib()
+    rv = Rendezvous()
+    rank, world, local_rank = rv.rank, rv.world, rv.local_rank
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
     ndev = device_count()
     if ndev < 1:
         sys.exit("bench.py: no HIP device visible -- this engine has no CPU path to fall back to")
     device_select(local_rank % ndev)
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = rv.barrier
 
     # ---- workload ------------------------------------------------------------------------------
     model = synth.make_config("config3_crowd")
     ni = args.instances_per_gpu
-    lo, hi = shard(ni * world, world, rank)
-    frames = (np.arange(lo, hi) * 3) % 1801                 # phase-shifted animation per instance
-    pals = synth.make_palettes(model, frames, seed=7 + rank)
+    lo, hi = shard_instances(ni * world, world, rank)
+    pals = synth.make_palettes(model, crowd_frames(lo, hi))   # phase-shifted animation per instance
     rates = synth.morph_weights(model.nm, 30)[0]
     layout = api.OUT_SOA if args.layout == "soa" else api.OUT_VERTEX32
     pos_scale = 1.0 if layout == api.OUT_SOA else 0.1
@@ -130,11 +114,7 @@ def main():
     assert ncalls == args.steps
     skin_avg = skin_total / ncalls
     morph_avg = morph_total / ncalls
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = rv.max(elapsed)
 
     total_vertices = float(ni) * world * model.nv * args.steps
     value = total_vertices / elapsed
@@ -164,6 +144,7 @@ def main():
     }
 
     if rank == 0:
+        result["roofline"].update(pmc_traffic(layout == api.OUT_SOA))
         result["device"] = device_name(local_rank % ndev)
         # practical ceilings on this box (SURVEY.md section 8d asks for them next to the spec peak)
         nb_ceiling = 1 << 30
@@ -206,11 +187,35 @@ def main():
     if d_b:
         d_b.free()
     dm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rv.close()
     if rank == 0:
         print(json.dumps(result))
+
+
+def pmc_traffic(is_default_layout: bool):
+    """HBM bytes per launch of the deform kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/config3_pmc_hbm_traffic.csv: FETCH_SIZE and WRITE_SIZE collected in separate
+    passes).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts wide streaming reads at
+    half their bytes -- the same file's 1 GiB copy_kernel row (FETCH = 524 299 KB) confirms it -- so the
+    read side is doubled; WRITE_SIZE is exact.  bench.py cannot drive PMC itself, hence a recorded
+    figure with its provenance, or null."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "config3_pmc_hbm_traffic.csv")))
+    if not files or not is_default_layout:
+        return {"traffic": None}
+    fetch = write = None
+    for row in csv.DictReader(open(files[-1])):
+        if "deform_kernel" in row["kernel"]:
+            if row["counter"] == "FETCH_SIZE":
+                fetch = float(row["mean_KB"]) * 1024
+            elif row["counter"] == "WRITE_SIZE":
+                write = float(row["mean_KB"]) * 1024
+    if fetch is None or write is None:
+        return {"traffic": None}
+    return {"traffic": write + 2 * fetch, "traffic_detail": {
+        "write_bytes": write, "fetch_bytes_reported": fetch, "fetch_correction": 2.0,
+        "source": os.path.relpath(files[-1], ROOT)}}
 
 
 def time_calls(dm, fn, iters, warm=3):

@@ -59,5 +59,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_EXAMPLE = os.path.join(HOST_DIR, "frame_loop_example")
+
+
+def build_host_example(force: bool = False) -> str:
+    """The C++ host mirror's runnable example (g++ only: the host side needs no HIP headers)."""
+    src = os.path.join(HOST_DIR, "frame_loop_example.cpp")
+    hdr = os.path.join(HOST_DIR, "mmdx_poser.hpp")
+    if (not force and os.path.exists(HOST_EXAMPLE) and
+            all(os.path.getmtime(d) <= os.path.getmtime(HOST_EXAMPLE) for d in (src, hdr, LIB))):
+        return HOST_EXAMPLE
+    build()
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", src,
+           "-I" + os.path.join(HERE, "..", "include"), "-L" + HERE, "-lmmdx", "-Wl,-rpath,$ORIGIN/..",
+           "-o", HOST_EXAMPLE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("g++ failed for host/frame_loop_example.cpp")
+    return HOST_EXAMPLE
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host_example(force="--force" in sys.argv))

@@ -1,0 +1,61 @@
+"""CPU: the N>1 path (instance-sharded crowd, one process per device, gloo rendezvous) with
+world_size 2 and 3, against a single-process oracle run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from simple_mmd_renderer_amd import synth
+from simple_mmd_renderer_amd.crowd import crowd_frames, shard_instances
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shards_tile_the_crowd_exactly():
+    for total in (1, 7, 1024, 8192, 1000):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [shard_instances(total, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    # weak scaling as bench.py uses it: 1024 per rank
+    assert shard_instances(1024 * 8, 8, 3) == (3072, 4096)
+    with pytest.raises(ValueError):
+        shard_instances(10, 2, 2)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_crowd_equals_single_process(oracle, tmp_path, world):
+    total = 11
+    out = tmp_path / "result.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(out), str(total)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.load(open(out))
+    assert res["world"] == world and res["n_total"] == total
+    assert res["slowest"] >= res["rank0_elapsed"] + 0.01 * (world - 1) - 1e-3   # max over ranks, not rank 0's
+    # single-process reference over the whole crowd
+    model = synth.make_model(1500, 40, 6, 100, seed=99)
+    rates = synth.morph_weights(model.nm, 30)[0]
+    pals = synth.make_palettes(model, crowd_frames(0, total))
+    skin = oracle.normalize(model)
+    vimg = oracle.morph(model, rates)
+    want = []
+    for i in range(total):
+        pos, nrm = oracle.skin(model, pals[i], vimg, skin)
+        want.append(synth.checksum64(np.concatenate([pos.ravel(), nrm.ravel()])))
+    assert res["checksums"] == want

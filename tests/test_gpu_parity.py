@@ -288,3 +288,16 @@ def test_config5_fp16_full_size_sample(oracle):
             ep, en = oracle_expect(oracle, q, rates[i], pals[i])
             assert np.array_equal(pos16[i].view(np.uint16), ep.astype(np.float16).view(np.uint16))
             gu.assert_bits_equal(nrm[i], en, "nrm")
+
+
+def test_cpp_host_mirror_frame_loop():
+    """The C++ host side (host/mmdx_poser.hpp: mmd::Poser-shaped class over the C ABI) runs the
+    reference's per-frame sequence; the program checks pose_image*0.1f == vertex stream itself."""
+    import subprocess
+    from simple_mmd_renderer_amd import build
+    exe = build.build_host_example()
+    r = subprocess.run([exe, "20000", "30"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "frames=30 nv=20000" in r.stdout and "MISMATCH" not in r.stdout
+    again = subprocess.run([exe, "20000", "30"], capture_output=True, text=True, timeout=120)
+    assert again.stdout == r.stdout            # deterministic, run to run
