@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmmdx.so")
+LIB_PATH = os.environ.get("MMDX_LIB") or os.path.join(HERE, "libmmdx.so")   # MMDX_LIB: A/B of builds (tools/)
 
 OK = 0
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5: "OUT_OF_MEMORY",

@@ -338,6 +338,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     dp.nv = p.nv; dp.nb = p.nb; dp.ns = p.ns; dp.ni = ni;
     dp.pos_scale = a->pos_scale;
     dp.pal_stride = p.max_tile_bones * 3;
+    dp.finite_offsets = p.finite_offsets ? 1u : 0u;
+    dp.interleave = uint32_t(env_int("MMDX_INTERLEAVE", 1));
 #ifdef MMDX_ABLATE
     dp.ablate = uint32_t(env_int("MMDX_ABLATE", 0));
 #endif

@@ -198,19 +198,34 @@ struct Slot {
     bool act;
 };
 
+// One CSR row, entries in the reference's accumulation order.  Four entry loads are issued before the
+// first is consumed (rows are short -- 8 to 16 entries -- and every load is an L2 round trip: with one
+// load per iteration the gather is a chain of latencies); the body still sees the entries one by one,
+// in order, so the rounding sequence is the reference's.
 template <bool F16>
-__device__ __forceinline__ void load_entry(const void *entries, uint32_t e, v2f &oxy, float &oz,
-                                           uint32_t &slot) {
-    if constexpr (F16) {
-        const uint2 r = reinterpret_cast<const uint2 *>(entries)[e];
-        oxy = v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)};
-        oz = h2f(r.y & 0xffffu);
-        slot = r.y >> 16;
-    } else {
-        const float4 r = reinterpret_cast<const float4 *>(entries)[e];
-        oxy = v2f{r.x, r.y};
-        oz = r.z;
-        slot = __float_as_uint(r.w);
+struct RawEntry { using type = float4; };
+template <>
+struct RawEntry<true> { using type = uint2; };
+
+template <bool F16, typename Body>
+__device__ __forceinline__ void for_row(const void *entries, uint32_t rb, uint32_t re, Body body) {
+    using Raw = typename RawEntry<F16>::type;
+    const Raw *ent = reinterpret_cast<const Raw *>(entries);
+    auto apply = [&](const Raw r) {
+        if constexpr (F16) {
+            body(v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)}, h2f(r.y & 0xffffu), uint32_t(r.y >> 16));
+        } else {
+            body(v2f{r.x, r.y}, r.z, __float_as_uint(r.w));
+        }
+    };
+    for (uint32_t e = rb; e < re; e += 4) {
+        const uint32_t last = re - 1;
+        const Raw r0 = ent[e], r1 = ent[min(e + 1, last)], r2 = ent[min(e + 2, last)],
+                  r3 = ent[min(e + 3, last)];
+        apply(r0);
+        if (e + 1 < re) apply(r1);
+        if (e + 2 < re) apply(r2);
+        if (e + 3 < re) apply(r3);
     }
 }
 
@@ -221,10 +236,37 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     constexpr int VPT = int(kTileVerts) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const TileHdr &th = p.tiles[blockIdx.x];
+    // XCD-aware work mapping (speed only, never correctness): workgroup ids are dealt round-robin over
+    // the 8 XCDs, each with a private 4 MiB L2.  XCD x gets a CONTIGUOUS range of tiles for all
+    // instance groups, tile index fastest, so the ~96 workgroups resident on one XCD are (its ~12 tiles)
+    // x (8 groups): a tile's static streams and the palette rows neighbouring tiles share are fetched
+    // into that L2 once instead of once per XCD.  Tiles left over by ntiles % 8 are split by groups.
+    uint32_t tile, grp;
+    {
+        const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+        const uint32_t T = p.ntiles >> 3, main_count = T * p.ngroups;
+        if (k < main_count) {
+            grp = k / T;
+            tile = xcd * T + (k - grp * T);
+        } else {
+            const uint32_t r = xcd * p.rem_per_xcd + (k - main_count);
+            if (r >= (p.ntiles & 7u) * p.ngroups) return;       // padding workgroup
+            const uint32_t rt = r / p.ngroups;
+            tile = 8u * T + rt;
+            grp = r - rt * p.ngroups;
+        }
+    }
+    const TileHdr &th = p.tiles[tile];
     const uint32_t v0 = th.v0, nvt = th.nv, n1 = th.n1, n12 = th.n1 + th.n2, nbt = th.nbt;
-    const uint32_t inst0 = blockIdx.y * p.group;
-    const uint32_t gcount = min(p.group, p.ni - inst0);
+    // Instances of this workgroup.  Blocked: grp*group + g.  Interleaved (crowd modes): g*ngroups + grp,
+    // so that the workgroups running at the same time (neighbouring grp) write NEIGHBOURING instances:
+    // chip-wide the stores then sweep a few contiguous megabytes of each output array, like a linear
+    // fill, instead of 8+ streams 9.6 MB apart.
+    const bool ilv = (MORPH == kMorphNone || MORPH == kMorphShared) && p.interleave != 0;
+    const uint32_t inst0 = ilv ? grp : grp * p.group;
+    const uint32_t istep = ilv ? p.ngroups : 1u;
+    const uint32_t gcount = ilv ? (p.ni > grp ? min(p.group, (p.ni - grp + p.ngroups - 1) / p.ngroups) : 0u)
+                                : min(p.group, p.ni - inst0);
     float4 *pal = reinterpret_cast<float4 *>(smem);
     unsigned char *stage = smem + p.stage_off;
     constexpr uint32_t kStage = stage_bytes(LAYOUT);
@@ -237,7 +279,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         const uint32_t g = idx / nbt, lb = idx - g * nbt;
         const uint32_t bone = p.bone_list[th.bone_off + lb];
         const float4 *src =
-            reinterpret_cast<const float4 *>(p.palettes + (size_t(inst0 + g) * p.nb + bone) * 16);
+            reinterpret_cast<const float4 *>(p.palettes + (size_t(inst0 + g * istep) * p.nb + bone) * 16);
         const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
         float4 *dst = pal + size_t(g) * p.pal_stride + lb * 3;
         dst[0] = make_float4(r0.x, r0.y, r1.x, r1.y);
@@ -315,7 +357,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT]) {
         const float4 *P = pal + size_t(g) * p.pal_stride;
         unsigned char *img = stage + buf * kStage;
-        const size_t vbase = size_t(inst0 + g) * p.nv + v0;  // first output vertex of this tile
+        const size_t vbase = size_t(inst0 + g * istep) * p.nv + v0;  // first output vertex of this tile
         const bool al = p.out_aligned != 0;
         const uint32_t sh4 = al ? uint32_t((vbase * 3) & 3) : 0u;
         const uint32_t sh8 = al ? uint32_t((vbase * 3) & 7) : 0u;
@@ -439,12 +481,10 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         for (int k = 0; k < VPT; ++k) {
             v2f dxy = v2f{0.f, 0.f};
             float dz = 0.f;
-            for (uint32_t e = sl[k].rb; e < sl[k].re; ++e) {
-                v2f oxy; float oz; uint32_t slot;
-                load_entry<F16>(p.entries, e, oxy, oz, slot);
+            for_row<F16>(p.entries, sl[k].rb, sl[k].re, [&](v2f oxy, float oz, uint32_t slot) {
                 const float w = wl[slot];
                 if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
-            }
+            });
             cxy[k] = sl[k].pxy + dxy; cz[k] = sl[k].pz + dz;
         }
         run_instance(0, cxy, cz);
@@ -458,14 +498,25 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             for (int k = 0; k < VPT; ++k) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { dxy[k][j] = v2f{0.f, 0.f}; dz[k][j] = 0.f; }
-                for (uint32_t e = sl[k].rb; e < sl[k].re; ++e) {
-                    v2f oxy; float oz; uint32_t slot;
-                    load_entry<F16>(p.entries, e, oxy, oz, slot);
-                    const float4 w = wq[slot];
-                    if (!(w.x < kMorphEps)) { dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x; }
-                    if (!(w.y < kMorphEps)) { dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y; }
-                    if (!(w.z < kMorphEps)) { dxy[k][2] += oxy * w.z; dz[k][2] += oz * w.z; }
-                    if (!(w.w < kMorphEps)) { dxy[k][3] += oxy * w.w; dz[k][3] += oz * w.w; }
+                if (p.finite_offsets) {
+                    // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
+                    // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
+                    // the image bit-for-bit unchanged: the skip needs no branch.
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].re, [&](v2f oxy, float oz, uint32_t slot) {
+                        const float4 w = wq[slot];
+                        dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x;
+                        dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y;
+                        dxy[k][2] += oxy * w.z; dz[k][2] += oz * w.z;
+                        dxy[k][3] += oxy * w.w; dz[k][3] += oz * w.w;
+                    });
+                } else {
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].re, [&](v2f oxy, float oz, uint32_t slot) {
+                        const float4 w = wq[slot];
+                        if (!(w.x < kMorphEps)) { dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x; }
+                        if (!(w.y < kMorphEps)) { dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y; }
+                        if (!(w.z < kMorphEps)) { dxy[k][2] += oxy * w.z; dz[k][2] += oz * w.z; }
+                        if (!(w.w < kMorphEps)) { dxy[k][3] += oxy * w.w; dz[k][3] += oz * w.w; }
+                    });
                 }
             }
 #pragma unroll
@@ -499,13 +550,10 @@ __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParam
     }
     v2f dxy = v2f{0.f, 0.f};
     float dz = 0.f;
-    const uint32_t rb = p.row_ptr[gs], re = p.row_ptr[gs + 1];
-    for (uint32_t e = rb; e < re; ++e) {
-        v2f oxy; float oz; uint32_t slot;
-        load_entry<F16>(p.entries, e, oxy, oz, slot);
+    for_row<F16>(p.entries, p.row_ptr[gs], p.row_ptr[gs + 1], [&](v2f oxy, float oz, uint32_t slot) {
         const float w = p.wslot[slot];
         if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
-    }
+    });
     p.morphed[gs * 3] = bx + dxy.x;
     p.morphed[gs * 3 + 1] = by + dxy.y;
     p.morphed[gs * 3 + 2] = bz + dz;
@@ -603,8 +651,12 @@ hipError_t launch_deform(int threads, int layout, int morph, bool f16, const Def
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream) {
     KernelFn fn = pick(threads, layout, morph, f16);
     if (!fn) return hipErrorInvalidValue;
-    const dim3 grid(ntiles, (p.ni + p.group - 1) / p.group);
-    hipLaunchKernelGGL(fn, grid, dim3((threads == 256 || kTileVerts < 512) ? 256 : 512), lds_bytes, stream, p);
+    DeformParams q = p;
+    q.ntiles = ntiles;
+    q.ngroups = (p.ni + p.group - 1) / p.group;
+    q.rem_per_xcd = ((ntiles & 7u) * q.ngroups + 7u) / 8u;
+    const dim3 grid(8u * ((ntiles >> 3) * q.ngroups + q.rem_per_xcd));
+    hipLaunchKernelGGL(fn, grid, dim3((threads == 256 || kTileVerts < 512) ? 256 : 512), lds_bytes, stream, q);
     return hipGetLastError();
 }
 

@@ -43,11 +43,14 @@ struct DeformParams {
     void *out_b;
     uint32_t nv, nb, ns, ni;
     uint32_t group;              // instances per workgroup (multiple of 4 for kMorphFused4)
+    uint32_t ntiles, ngroups, rem_per_xcd;  // filled by launch_deform (XCD-aware work mapping)
     uint32_t pal_stride;         // float4 per instance in LDS (= max_tile_bones * 3)
     uint32_t stage_off;          // byte offsets inside dynamic LDS
     uint32_t w_off;
     float pos_scale;
     uint32_t out_aligned;        // out_a and out_b are 16-byte aligned
+    uint32_t finite_offsets;     // every vertex-morph offset is finite (branch-free morph skip is exact)
+    uint32_t interleave;         // crowd modes: instance = g*ngroups + grp instead of grp*group + g
     uint32_t ablate;             // MMDX_ABLATE builds only (tools/): bit0 no global stores,
                                  // bit1 no skinning math, bit2 no staging/copy-out at all
 };

@@ -305,6 +305,14 @@ mmdx_status build_plan(const mmdx_model_desc &d, Plan &p, std::string &err) {
         for (uint32_t j = d.morph_offset[m]; j < d.morph_offset[m + 1]; ++j) {
             const uint32_t at = cursor[gs_of[d.morph_index[j]]]++;
             const float *o = d.morph_value + 3 * size_t(j);
+            for (int c = 0; c < 3; ++c) {
+                uint32_t bits;
+                std::memcpy(&bits, o + c, 4);
+                // inf / NaN, or a finite f32 that rounds to inf as binary16
+                if ((bits & 0x7f800000u) == 0x7f800000u ||
+                    (p.f16 && (f32_to_f16_rne(o[c]) & 0x7c00u) == 0x7c00u))
+                    p.finite_offsets = false;
+            }
             if (p.f16) {
                 uint16_t *e = p.entries16.data() + 4 * size_t(at);
                 e[0] = f32_to_f16_rne(o[0]); e[1] = f32_to_f16_rne(o[1]); e[2] = f32_to_f16_rne(o[2]);

@@ -50,6 +50,7 @@ struct Plan {
     uint32_t n1 = 0, n2 = 0, n4 = 0;
     uint32_t max_tile_bones = 0;
     bool f16 = false;
+    bool finite_offsets = true;   // no inf/NaN among the vertex-morph offsets (after f16 rounding)
 
     // post-Normalize skin in ORIGINAL order (class 0/1/2, ids, weights)
     std::vector<int32_t> cls, ids;

@@ -158,6 +158,35 @@ def test_no_morph_model_and_empty_rows(oracle):
         gu.assert_bits_equal(nrm, en, "nrm")
 
 
+def test_nonfinite_morph_offsets_keep_skip_semantics(oracle):
+    """inf / NaN morph offsets switch the kernels to the predicated skip (a skipped morph must not
+    turn inf*0 into NaN); finite-offset models take the branch-free path.  Both against the oracle."""
+    m = synth.make_model(2000, 30, 6, 150, seed=404)
+    m.morph_value[m.morph_off[2]:m.morph_off[3], 0] = np.inf        # morph 2: +inf x offsets
+    m.morph_value[m.morph_off[4] + 3, 1] = np.nan                    # morph 4: one NaN
+    rates = np.array([[0.3, 0.0, 0.0, 0.7, 5e-8, 1.0],               # 2 and 4 skipped -> finite result
+                      [0.3, 0.2, 0.5, 0.0, 0.0, 0.4],                # morph 2 applied -> +-inf appears
+                      [0.0, 0.0, 0.0, 0.0, 1.0, 0.0],                # morph 4 applied -> NaN appears
+                      [1.0, 1.0, 0.0, 1.0, 0.0, 1.0],
+                      [0.1, 0.0, 0.0, 0.0, 0.0, 0.0]], np.float32)
+    pals = synth.make_palettes(m, np.arange(5))
+
+    def same(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        return np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)))
+
+    with DeformModel(m) as dm:
+        pos, nrm = dm.deform_batched(rates, pals)                    # fused, 4 instances per pass
+        for i in range(5):
+            ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+            assert same(pos[i], ep) and same(nrm[i], en), f"instance {i}"
+            sp, sn = dm.deform(rates[i], pals[i])                    # fused, single instance
+            assert same(sp, ep) and same(sn, en)
+            cp, cn = dm.deform_batched(rates[i], pals, shared_weights=True)   # shared morph pass
+            assert same(cp[i], ep) and same(cn[i], en)
+        assert np.isfinite(pos[0]).all() and not np.isfinite(pos[1]).all() and np.isnan(pos[2]).any()
+
+
 def test_device_resident_io_matches_host_io(oracle):
     """The bench path: palettes, weights and outputs all resident in HBM."""
     m = synth.make_model(5000, 120, 10, 400, seed=31)
