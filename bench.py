@@ -158,6 +158,10 @@ def main():
         result["roofline"]["measured_fill_GBs"] = nb_ceiling / (ms.value * 1e-3) / 1e9
         src.free()
         dst.free()
+        if layout == api.OUT_SOA and model.nv % 4 == 0:
+            api.check(api.lib().mmdx_bench_store_pattern(d_a.ptr, d_b.ptr, model.nv, ni, 10, C.byref(ms)))
+            result["roofline"]["measured_store_pattern_GBs"] = ni * model.nv * 24 / (ms.value * 1e-3) / 1e9
+            step()      # leave real results in the output buffers
 
     # ---- CPU baseline: rank 0, N=1 only ------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -142,13 +142,15 @@ typedef struct mmdx_model_info {
     uint32_t struct_size;
     uint32_t n_vertices, n_bones, n_morphs;
     uint32_t n_slots;          /* vertex-morph applications in the reference's traversal order      */
-    uint32_t n_entries;        /* vertex-morph entries after group expansion (CSR length)           */
+    uint32_t n_entries;        /* vertex-morph entries after group expansion                       */
+    uint32_t n_entries_padded; /* ... incl. the padding of the sliced-ELL gather table               */
     uint32_t n_tiles, tile_vertices;
     uint32_t n_bdef1, n_bdef2, n_bdef4; /* after optional Normalize; SDEF/unknown count as bdef2   */
     uint32_t max_tile_bones;
     uint64_t device_bytes;     /* static streams resident in HBM                                   */
     uint32_t device_ordinal;
     uint32_t flags;
+    uint32_t reserved0;
 } mmdx_model_info;
 
 /* ---- library / device ------------------------------------------------------------------------ */
@@ -212,6 +214,11 @@ MMDX_API mmdx_status mmdx_bench_copy(void *dst_device, const void *src_device, s
                                      int32_t iterations, float *avg_ms);
 MMDX_API mmdx_status mmdx_bench_fill(void *dst_device, size_t bytes, int32_t iterations,
                                      float *avg_ms);
+/* Store-only replay of the crowd kernel's SoA output pattern (two arrays of n_instances x
+ * n_vertices x 12 bytes, 6 KiB pieces): the write ceiling of THAT pattern on this box. */
+MMDX_API mmdx_status mmdx_bench_store_pattern(void *out_a_device, void *out_b_device,
+                                              uint32_t n_vertices, uint32_t n_instances,
+                                              int32_t iterations, float *avg_ms);
 
 #ifdef __cplusplus
 }

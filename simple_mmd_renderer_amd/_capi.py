@@ -46,12 +46,12 @@ class DeformArgs(C.Structure):
 class ModelInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32),
                 ("n_vertices", C.c_uint32), ("n_bones", C.c_uint32), ("n_morphs", C.c_uint32),
-                ("n_slots", C.c_uint32), ("n_entries", C.c_uint32),
+                ("n_slots", C.c_uint32), ("n_entries", C.c_uint32), ("n_entries_padded", C.c_uint32),
                 ("n_tiles", C.c_uint32), ("tile_vertices", C.c_uint32),
                 ("n_bdef1", C.c_uint32), ("n_bdef2", C.c_uint32), ("n_bdef4", C.c_uint32),
                 ("max_tile_bones", C.c_uint32),
                 ("device_bytes", C.c_uint64),
-                ("device_ordinal", C.c_uint32), ("flags", C.c_uint32)]
+                ("device_ordinal", C.c_uint32), ("flags", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class MmdxError(RuntimeError):
@@ -89,6 +89,7 @@ SIGNATURES = {
     "mmdx_device_synchronize": (C.c_int32, []),
     "mmdx_bench_copy": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
     "mmdx_bench_fill": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
+    "mmdx_bench_store_pattern": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, _f32p]),
 }
 
 _lib = None

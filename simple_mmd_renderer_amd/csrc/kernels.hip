@@ -193,24 +193,25 @@ struct Slot {
     float w0, w1, w2, w3;
     uint32_t b0, b1, b2, b3;  // float4 index of the bone's entry inside one instance's palette
     uint32_t perm;
-    uint32_t rb, re;          // CSR row [rb, re)
+    uint32_t rb, rlen;        // morph-table row: first entry (incl. lane), padded length
     int cls;
     bool act;
 };
 
-// One CSR row, entries in the reference's accumulation order.  Four entry loads are issued before the
-// first is consumed (rows are short -- 8 to 16 entries -- and every load is an L2 round trip: with one
-// load per iteration the gather is a chain of latencies); the body still sees the entries one by one,
-// in order, so the rounding sequence is the reference's.
+// One row of the sliced-ELL morph table (plan.cpp): entry j of this lane's row sits at
+// base + j*64 (base already includes the lane), `len` is the slice's padded row length and is
+// wave-uniform.  Four independent, fully coalesced loads are issued before the first entry is
+// consumed; the body still sees the entries one by one, in order, so the rounding sequence is the
+// reference's.  Padding entries carry the dummy slot NS whose weight is always 0.
 template <bool F16>
 struct RawEntry { using type = float4; };
 template <>
 struct RawEntry<true> { using type = uint2; };
 
 template <bool F16, typename Body>
-__device__ __forceinline__ void for_row(const void *entries, uint32_t rb, uint32_t re, Body body) {
+__device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint32_t len, Body body) {
     using Raw = typename RawEntry<F16>::type;
-    const Raw *ent = reinterpret_cast<const Raw *>(entries);
+    const Raw *ent = reinterpret_cast<const Raw *>(entries) + base;
     auto apply = [&](const Raw r) {
         if constexpr (F16) {
             body(v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)}, h2f(r.y & 0xffffu), uint32_t(r.y >> 16));
@@ -218,14 +219,14 @@ __device__ __forceinline__ void for_row(const void *entries, uint32_t rb, uint32
             body(v2f{r.x, r.y}, r.z, __float_as_uint(r.w));
         }
     };
-    for (uint32_t e = rb; e < re; e += 4) {
-        const uint32_t last = re - 1;
-        const Raw r0 = ent[e], r1 = ent[min(e + 1, last)], r2 = ent[min(e + 2, last)],
-                  r3 = ent[min(e + 3, last)];
+    for (uint32_t j = 0; j < len; j += 4) {
+        const uint32_t last = len - 1;
+        const Raw r0 = ent[size_t(j) * 64], r1 = ent[size_t(min(j + 1, last)) * 64],
+                  r2 = ent[size_t(min(j + 2, last)) * 64], r3 = ent[size_t(min(j + 3, last)) * 64];
         apply(r0);
-        if (e + 1 < re) apply(r1);
-        if (e + 2 < re) apply(r2);
-        if (e + 3 < re) apply(r3);
+        if (j + 1 < len) apply(r1);
+        if (j + 2 < len) apply(r2);
+        if (j + 3 < len) apply(r3);
     }
 }
 
@@ -289,11 +290,11 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     // 2. morph slot weights of the group -> LDS
     if constexpr (MORPH == kMorphFused1) {
         float *wl = reinterpret_cast<float *>(smem + p.w_off);
-        for (uint32_t s = tid; s < p.ns; s += THREADS) wl[s] = p.wslot[size_t(inst0) * p.ns + s];
+        for (uint32_t s = tid; s <= p.ns; s += THREADS) wl[s] = p.wslot[size_t(inst0) * (p.ns + 1) + s];
     } else if constexpr (MORPH == kMorphFused4) {
         float4 *wl4 = reinterpret_cast<float4 *>(smem + p.w_off);
-        const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t(inst0 / 4) * p.ns;
-        const uint32_t n = ((gcount + 3) / 4) * p.ns;
+        const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t(inst0 / 4) * (p.ns + 1);
+        const uint32_t n = ((gcount + 3) / 4) * (p.ns + 1);
         for (uint32_t i = tid; i < n; i += THREADS) wl4[i] = src[i];
     }
 
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         q.pz = q.nz = 0.f;
         q.w0 = q.w1 = q.w2 = q.w3 = 0.f;
         q.b0 = q.b1 = q.b2 = q.b3 = 0;
-        q.perm = 0; q.rb = q.re = 0;
+        q.perm = 0; q.rb = q.rlen = 0;
 #ifdef MMDX_ABLATE
         if (p.ablate & 64u) { q.perm = s; continue; }
 #endif
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             }
             q.perm = p.perm[gs];
             if constexpr (MORPH == kMorphFused1 || MORPH == kMorphFused4) {
-                q.rb = p.row_ptr[gs]; q.re = p.row_ptr[gs + 1];
+                const uint2 sl2 = p.ell[gs >> 6];            // slice of this wave-slot (wave-uniform)
+                q.rb = sl2.x + uint32_t(gs & 63); q.rlen = sl2.y;
             }
             if (q.cls == 0) {
                 q.b0 = uint32_t(p.skin1[th.skin1_off + s]) * 3;
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         for (int k = 0; k < VPT; ++k) {
             v2f dxy = v2f{0.f, 0.f};
             float dz = 0.f;
-            for_row<F16>(p.entries, sl[k].rb, sl[k].re, [&](v2f oxy, float oz, uint32_t slot) {
+            for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
                 const float w = wl[slot];
                 if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
             });
@@ -493,16 +495,28 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         for (uint32_t g0 = 0; g0 < gcount; g0 += 4) {
             v2f dxy[VPT][4];
             float dz[VPT][4];
-            const float4 *wq = wl4 + size_t(g0 / 4) * p.ns;
+            const float4 *wq = wl4 + size_t(g0 / 4) * (p.ns + 1);
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { dxy[k][j] = v2f{0.f, 0.f}; dz[k][j] = 0.f; }
+#ifdef MMDX_ABLATE
+                if (p.ablate & 128u) {           // no morph gather at all
+                } else if (p.ablate & 256u) {    // gather without the LDS weight lookups
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
+                        const float w = __uint_as_float(slot | 0x3f000000u);
+                        dxy[k][0] += oxy * w; dz[k][0] += oz * w;
+                        dxy[k][1] += oxy * w; dz[k][1] += oz * w;
+                        dxy[k][2] += oxy * w; dz[k][2] += oz * w;
+                        dxy[k][3] += oxy * w; dz[k][3] += oz * w;
+                    });
+                } else
+#endif
                 if (p.finite_offsets) {
                     // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
                     // the image bit-for-bit unchanged: the skip needs no branch.
-                    for_row<F16>(p.entries, sl[k].rb, sl[k].re, [&](v2f oxy, float oz, uint32_t slot) {
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
                         const float4 w = wq[slot];
                         dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x;
                         dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y;
@@ -510,7 +524,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                         dxy[k][3] += oxy * w.w; dz[k][3] += oz * w.w;
                     });
                 } else {
-                    for_row<F16>(p.entries, sl[k].rb, sl[k].re, [&](v2f oxy, float oz, uint32_t slot) {
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
                         const float4 w = wq[slot];
                         if (!(w.x < kMorphEps)) { dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x; }
                         if (!(w.y < kMorphEps)) { dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y; }
@@ -536,8 +550,32 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
 }
 
 // ---- shared morph pass: morphed[gs] = base[gs] + sum(offset*rate), once per call ------------------
-template <bool F16>
-__global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParams p) {
+// FUSED_FLATTEN: every workgroup first evaluates the group-morph chains of all slots into LDS
+// (UpdateMorphTransform's recursion; NS is a few hundred), saving the separate flatten launch.
+__device__ __forceinline__ float slot_weight(const float *rates, const uint32_t *slot_top,
+                                             const uint32_t *chain_off, const float *chain_rate,
+                                             uint32_t s) {
+    float r = rates[slot_top[s]];
+    bool skip = r < kMorphEps;
+    for (uint32_t c = chain_off[s]; !skip && c < chain_off[s + 1]; ++c) {
+        r = chain_rate[c] * r;
+        skip = r < kMorphEps;
+    }
+    return skip ? 0.f : r;
+}
+
+template <bool F16, bool FUSED_FLATTEN>
+__global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParams p,
+                                                               const FlattenParams f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const float *wsl = p.wslot;
+    if constexpr (FUSED_FLATTEN) {
+        float *wl = reinterpret_cast<float *>(smem);
+        for (uint32_t s = threadIdx.x; s <= f.ns; s += kThreads)     // slot ns = padding, weight 0
+            wl[s] = s < f.ns ? slot_weight(f.rates, f.slot_top, f.chain_off, f.chain_rate, s) : 0.f;
+        __syncthreads();
+        wsl = wl;
+    }
     const size_t gs = size_t(blockIdx.x) * kThreads + threadIdx.x;
     if (gs >= p.nv) return;
     float bx, by, bz;
@@ -550,8 +588,9 @@ __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParam
     }
     v2f dxy = v2f{0.f, 0.f};
     float dz = 0.f;
-    for_row<F16>(p.entries, p.row_ptr[gs], p.row_ptr[gs + 1], [&](v2f oxy, float oz, uint32_t slot) {
-        const float w = p.wslot[slot];
+    const uint2 sl2 = p.ell[gs >> 6];
+    for_row<F16>(p.entries, sl2.x + uint32_t(gs & 63), sl2.y, [&](v2f oxy, float oz, uint32_t slot) {
+        const float w = wsl[slot];
         if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
     });
     p.morphed[gs * 3] = bx + dxy.x;
@@ -561,21 +600,15 @@ __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParam
 
 // ---- group-morph flattening on the device (UpdateMorphTransform's recursion, per slot) ------------
 __global__ __launch_bounds__(kThreads) void flatten_kernel(const FlattenParams f) {
+    // output rows have ns+1 columns: column ns is the padding slot of the morph table, always 0
     const size_t idx = size_t(blockIdx.x) * kThreads + threadIdx.x;
-    const uint32_t rows = f.quad ? ((f.niw + 3) / 4) * 4 : f.niw;
-    if (idx >= size_t(rows) * f.ns) return;
-    const uint32_t i = uint32_t(idx / f.ns), s = uint32_t(idx - size_t(i) * f.ns);
+    const uint32_t rows = f.quad ? ((f.niw + 3) / 4) * 4 : f.niw, cols = f.ns + 1;
+    if (idx >= size_t(rows) * cols) return;
+    const uint32_t i = uint32_t(idx / cols), s = uint32_t(idx - size_t(i) * cols);
     float out = 0.f;
-    if (i < f.niw) {
-        float r = f.rates[size_t(i) * f.nm + f.slot_top[s]];
-        bool skip = r < kMorphEps;
-        for (uint32_t c = f.chain_off[s]; !skip && c < f.chain_off[s + 1]; ++c) {
-            r = f.chain_rate[c] * r;
-            skip = r < kMorphEps;
-        }
-        out = skip ? 0.f : r;
-    }
-    if (f.quad) f.out[(size_t(i / 4) * f.ns + s) * 4 + (i & 3)] = out;
+    if (i < f.niw && s < f.ns)
+        out = slot_weight(f.rates + size_t(i) * f.nm, f.slot_top, f.chain_off, f.chain_rate, s);
+    if (f.quad) f.out[(size_t(i / 4) * cols + s) * 4 + (i & 3)] = out;
     else f.out[idx] = out;
 }
 
@@ -590,6 +623,24 @@ __global__ __launch_bounds__(kThreads) void copy_kernel(float4 *dst, const float
 __global__ __launch_bounds__(kThreads) void fill_kernel(float4 *dst, size_t n) {
     const size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x;
     if (i < n) dst[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+// Store-only replay of the deform kernel's output pattern (SoA): workgroup = (512-vertex tile, group of
+// 16 instances) writing one 6 KiB piece into each of the two arrays per instance.  On some MI355X boxes
+// this two-array pattern runs at the linear-fill rate, on others ~25 % below it (tools/); bench.py
+// prints it as the ceiling the deform kernel can be held against on THAT box.
+__global__ __launch_bounds__(kThreads) void pattern_fill_kernel(float4 *a, float4 *b, uint32_t nv,
+                                                                uint32_t ni, uint32_t ntiles) {
+    const uint32_t tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
+    const uint32_t v0 = tile * kTileVerts, nvt = min(kTileVerts, nv - v0);
+    const uint32_t piece4 = nvt * 12 / 16;          // callers pass nv % 4 == 0
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (uint32_t g = grp * 16; g < min(ni, grp * 16 + 16); ++g) {
+        const size_t base = (size_t(g) * nv + v0) * 12 / 16;
+        for (uint32_t q = threadIdx.x; q < 2 * piece4; q += kThreads) {
+            if (q < piece4) a[base + q] = v; else b[base + q - piece4] = v;
+        }
+    }
 }
 
 using KernelFn = void (*)(const DeformParams);
@@ -627,8 +678,8 @@ size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile
     *stage_off = uint32_t(off);
     off += 2 * size_t(stage_bytes(layout));
     *w_off = uint32_t(off);
-    if (morph == kMorphFused1) off += (size_t(ns) * 4 + 15) / 16 * 16;
-    else if (morph == kMorphFused4) off += size_t((group + 3) / 4) * ns * 16;
+    if (morph == kMorphFused1) off += (size_t(ns + 1) * 4 + 15) / 16 * 16;
+    else if (morph == kMorphFused4) off += size_t((group + 3) / 4) * (ns + 1) * 16;
     return off;
 }
 
@@ -660,16 +711,31 @@ hipError_t launch_deform(int threads, int layout, int morph, bool f16, const Def
     return hipGetLastError();
 }
 
-hipError_t launch_morph_apply(bool f16, const DeformParams &p, hipStream_t stream) {
+hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenParams *fused,
+                              hipStream_t stream) {
     const dim3 grid((p.nv + kThreads - 1) / kThreads);
-    if (f16) hipLaunchKernelGGL(morph_apply_kernel<true>, grid, dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL(morph_apply_kernel<false>, grid, dim3(kThreads), 0, stream, p);
+    if (fused) {
+        const size_t lds = size_t(fused->ns + 1) * 4;
+        if (f16) hipLaunchKernelGGL((morph_apply_kernel<true, true>), grid, dim3(kThreads), lds, stream, p, *fused);
+        else hipLaunchKernelGGL((morph_apply_kernel<false, true>), grid, dim3(kThreads), lds, stream, p, *fused);
+    } else {
+        FlattenParams none{};
+        if (f16) hipLaunchKernelGGL((morph_apply_kernel<true, false>), grid, dim3(kThreads), 0, stream, p, none);
+        else hipLaunchKernelGGL((morph_apply_kernel<false, false>), grid, dim3(kThreads), 0, stream, p, none);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, hipStream_t stream) {
+    const uint32_t ntiles = (nv + kTileVerts - 1) / kTileVerts;
+    hipLaunchKernelGGL(pattern_fill_kernel, dim3(ntiles * ((ni + 15) / 16)), dim3(kThreads), 0, stream,
+                       reinterpret_cast<float4 *>(a), reinterpret_cast<float4 *>(b), nv, ni, ntiles);
     return hipGetLastError();
 }
 
 hipError_t launch_flatten(const FlattenParams &f, hipStream_t stream) {
     const uint32_t rows = f.quad ? ((f.niw + 3) / 4) * 4 : f.niw;
-    const size_t n = size_t(rows) * f.ns;
+    const size_t n = size_t(rows) * (f.ns + 1);
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(flatten_kernel, dim3(uint32_t((n + kThreads - 1) / kThreads)), dim3(kThreads),
                        0, stream, f);

@@ -31,13 +31,14 @@ struct DeformParams {
     const uint2 *skin4_ids;
     const float4 *skin4_w;
     const uint32_t *bone_list;
-    const uint32_t *row_ptr;     // [NV+1]
+    const uint2 *ell;            // [ntiles*8] {first entry, padded row length} per 64-slot slice
     const void *entries;         // float4 [NE]  |  f16 mode: uint2 [NE]
     // per call
     const float *palettes;       // [NI][NB][16] device
-    const float *wslot;          // kMorphFused1: f32 [NS] per instance (stride ns)
-                                 // kMorphFused4: float4 [ceil(NI/4)][NS] (instance quads)
-                                 // morph_apply : f32 [NS]
+    const float *wslot;          // rows of NS+1 weights (column NS = table padding, always 0):
+                                 // kMorphFused1: f32 [NI][NS+1]
+                                 // kMorphFused4: float4 [ceil(NI/4)][NS+1] (instance quads)
+                                 // morph_apply : f32 [NS+1]
     float *morphed;              // f32 [NV][3] sorted order (kMorphShared)
     void *out_a;
     void *out_b;
@@ -70,7 +71,11 @@ size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile
 
 hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_morph_apply(bool f16, const DeformParams &p, hipStream_t stream);
+// `fused` != nullptr: evaluate the slot weights inside the kernel (ns <= kMaxFusedSlots), no flatten launch
+hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenParams *fused,
+                              hipStream_t stream);
+constexpr uint32_t kMaxFusedSlots = 8192;
+hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, hipStream_t stream);
 hipError_t launch_flatten(const FlattenParams &p, hipStream_t stream);
 hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream);
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);

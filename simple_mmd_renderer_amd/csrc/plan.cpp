@@ -198,7 +198,25 @@ mmdx_status build_plan(const mmdx_model_desc &d, Plan &p, std::string &err) {
         }
     }
 
-    // ---- tiles: class sort, tile-local bone lists, per-class streams --------------------------
+    // ---- morph slots in the reference's traversal order; entries per vertex ----------------------
+    p.chain_off.push_back(0);
+    SlotBuilder sb{d, p, {}, {}, &err};
+    for (uint32_t m = 0; m < nm; ++m) {
+        mmdx_status st = sb.visit(m, m, 0);
+        if (st != MMDX_OK) return st;
+    }
+    p.ns = uint32_t(p.slot_top.size());
+    if (p.f16 && p.ns > 65534) {
+        err = "f16 morph entries need <= 65534 slots";
+        return MMDX_ERR_UNSUPPORTED;
+    }
+    std::vector<uint32_t> cnt(nv, 0);           // CSR row length of every original vertex
+    for (uint32_t s = 0; s < p.ns; ++s) {
+        const uint32_t m = sb.slot_morph[s];
+        for (uint32_t j = d.morph_offset[m]; j < d.morph_offset[m + 1]; ++j) ++cnt[d.morph_index[j]];
+    }
+
+    // ---- tiles: sort by (class, row length), tile-local bone lists, per-class streams -----------
     p.ntiles = (nv + kTileVerts - 1) / kTileVerts;
     p.tiles.resize(p.ntiles);
     if (p.f16) p.spos16.resize(size_t(nv) * 4); else p.spos.resize(size_t(nv) * 3);
@@ -210,7 +228,7 @@ mmdx_status build_plan(const mmdx_model_desc &d, Plan &p, std::string &err) {
     p.skin4_ids.reserve(size_t(p.n4) * 4); p.skin4_w.reserve(size_t(p.n4) * 4);
     std::vector<uint32_t> gs_of(nv);            // original vertex -> sorted global slot
     std::vector<int32_t> lut(nb, -1);           // global bone -> tile-local index
-    std::vector<uint32_t> tile_bones;
+    std::vector<uint32_t> tile_bones, order;
     for (uint32_t t = 0; t < p.ntiles; ++t) {
         TileHdr &h = p.tiles[t];
         std::memset(&h, 0, sizeof(h));
@@ -238,72 +256,92 @@ mmdx_status build_plan(const mmdx_model_desc &d, Plan &p, std::string &err) {
         h.skin1_off = uint32_t(p.skin1.size());
         h.skin2_off = uint32_t(p.skin2_w.size());
         h.skin4_off = uint32_t(p.skin4_w.size() / 4);
-        uint32_t s = 0;
-        for (int c = 0; c < 3; ++c) {
-            for (uint32_t l = 0; l < h.nv; ++l) {
-                const uint32_t v = h.v0 + l;
-                if (p.cls[v] != c) continue;
-                const uint32_t gs = h.v0 + s;
-                gs_of[v] = gs;
-                p.perm[gs] = uint16_t(l);
-                const int32_t *id = p.ids.data() + 4 * size_t(v);
-                const float *w = p.wts.data() + 4 * size_t(v);
-                if (c == 0) {
-                    p.skin1.push_back(uint16_t(lut[id[0]]));
-                } else if (c == 1) {
-                    p.skin2_ids.push_back(uint32_t(lut[id[0]]) | (uint32_t(lut[id[1]]) << 16));
-                    p.skin2_w.push_back(w[0]);
-                } else {
-                    for (int k = 0; k < 4; ++k) {
-                        p.skin4_ids.push_back(uint16_t(lut[id[k]]));
-                        p.skin4_w.push_back(w[k]);
-                    }
+        // class first (wave-uniform code paths), then longest morph row first (wave-uniform gather
+        // trip counts: the 64 rows of a wave-slot are padded to the longest), then original order
+        order.resize(h.nv);
+        for (uint32_t l = 0; l < h.nv; ++l) order[l] = l;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const uint32_t va = h.v0 + a, vb = h.v0 + b;
+            if (p.cls[va] != p.cls[vb]) return p.cls[va] < p.cls[vb];
+            if (cnt[va] != cnt[vb]) return cnt[va] > cnt[vb];
+            return a < b;
+        });
+        for (uint32_t s = 0; s < h.nv; ++s) {
+            const uint32_t l = order[s], v = h.v0 + l, gs = h.v0 + s;
+            const int c = p.cls[v];
+            gs_of[v] = gs;
+            p.perm[gs] = uint16_t(l);
+            const int32_t *id = p.ids.data() + 4 * size_t(v);
+            const float *w = p.wts.data() + 4 * size_t(v);
+            if (c == 0) {
+                p.skin1.push_back(uint16_t(lut[id[0]]));
+                ++h.n1;
+            } else if (c == 1) {
+                p.skin2_ids.push_back(uint32_t(lut[id[0]]) | (uint32_t(lut[id[1]]) << 16));
+                p.skin2_w.push_back(w[0]);
+                ++h.n2;
+            } else {
+                for (int k = 0; k < 4; ++k) {
+                    p.skin4_ids.push_back(uint16_t(lut[id[k]]));
+                    p.skin4_w.push_back(w[k]);
                 }
-                for (int k = 0; k < 3; ++k) {
-                    const float x = d.positions[3 * size_t(v) + k];
-                    if (p.f16) p.spos16[4 * size_t(gs) + k] = f32_to_f16_rne(x);
-                    else p.spos[3 * size_t(gs) + k] = x;
-                    p.snrm[3 * size_t(gs) + k] = d.normals[3 * size_t(v) + k];
-                }
-                if (p.f16) p.spos16[4 * size_t(gs) + 3] = 0;
-                if (d.uvs) {
-                    p.suv[2 * size_t(gs)] = d.uvs[2 * size_t(v)];
-                    p.suv[2 * size_t(gs) + 1] = d.uvs[2 * size_t(v) + 1];
-                }
-                ++s;
             }
-            if (c == 0) h.n1 = s;
-            else if (c == 1) h.n2 = s - h.n1;
+            for (int k = 0; k < 3; ++k) {
+                const float x = d.positions[3 * size_t(v) + k];
+                if (p.f16) p.spos16[4 * size_t(gs) + k] = f32_to_f16_rne(x);
+                else p.spos[3 * size_t(gs) + k] = x;
+                p.snrm[3 * size_t(gs) + k] = d.normals[3 * size_t(v) + k];
+            }
+            if (p.f16) p.spos16[4 * size_t(gs) + 3] = 0;
+            if (d.uvs) {
+                p.suv[2 * size_t(gs)] = d.uvs[2 * size_t(v)];
+                p.suv[2 * size_t(gs) + 1] = d.uvs[2 * size_t(v) + 1];
+            }
         }
         for (uint32_t k = 0; k < h.nbt; ++k) lut[tile_bones[k]] = -1;
     }
 
-    // ---- morph slots (reference traversal order) and vertex-major CSR ---------------------------
-    p.chain_off.push_back(0);
-    SlotBuilder sb{d, p, {}, {}, &err};
-    for (uint32_t m = 0; m < nm; ++m) {
-        mmdx_status st = sb.visit(m, m, 0);
-        if (st != MMDX_OK) return st;
+    // ---- morph gather table: sliced ELL -----------------------------------------------------------
+    // One slice per wave-slot (64 consecutive sorted slots).  Entry j of the 64 rows is stored
+    // contiguously (slice_base + j*64 + lane): one coalesced 1 KiB (f32) load per wave and j, all j
+    // independent of each other.  Rows are padded to the slice's longest row with the dummy entry
+    // {0,0,0, slot = NS}; slot NS always carries weight 0, so a pad adds (+0)*0 = +0 to a sum that is
+    // never -0: bit-exact no-op.  Per-row entry order = the reference's accumulation order.
+    const uint32_t nslices = p.ntiles * kSlicesPerTile;
+    p.ell.assign(size_t(nslices) * 2, 0);
+    uint64_t total = 0;
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+        const uint32_t g0 = sl * 64, g1 = std::min(g0 + 64, nv);
+        uint32_t len = 0;
+        for (uint32_t g = g0; g < g1; ++g) {
+            const uint32_t t = g / kTileVerts;
+            len = std::max(len, cnt[p.tiles[t].v0 + p.perm[g]]);
+        }
+        p.ell[2 * size_t(sl)] = uint32_t(total);
+        p.ell[2 * size_t(sl) + 1] = len;
+        total += uint64_t(len) * 64;
+        if (total > 0x7fffffffull) {
+            err = "morph gather table too large";
+            return MMDX_ERR_UNSUPPORTED;
+        }
     }
-    p.ns = uint32_t(p.slot_top.size());
-    if (p.f16 && p.ns > 65535) {
-        err = "f16 morph entries need <= 65535 slots";
-        return MMDX_ERR_UNSUPPORTED;
+    p.ne = uint32_t(total);
+    p.ne_real = 0;
+    if (p.f16) {
+        p.entries16.assign(size_t(p.ne) * 4, 0);
+        for (size_t e = 0; e < p.ne; ++e) p.entries16[4 * e + 3] = uint16_t(p.ns);
+    } else {
+        p.entries.assign(size_t(p.ne) * 4, 0.0f);
+        const uint32_t dummy = p.ns;
+        for (size_t e = 0; e < p.ne; ++e) std::memcpy(&p.entries[4 * e + 3], &dummy, 4);
     }
-    p.row_ptr.assign(size_t(nv) + 1, 0);
-    for (uint32_t s = 0; s < p.ns; ++s) {
-        const uint32_t m = sb.slot_morph[s];
-        for (uint32_t j = d.morph_offset[m]; j < d.morph_offset[m + 1]; ++j)
-            ++p.row_ptr[size_t(gs_of[d.morph_index[j]]) + 1];
-    }
-    for (uint32_t g = 0; g < nv; ++g) p.row_ptr[g + 1] += p.row_ptr[g];
-    p.ne = p.row_ptr[nv];
-    if (p.f16) p.entries16.resize(size_t(p.ne) * 4); else p.entries.resize(size_t(p.ne) * 4);
-    std::vector<uint32_t> cursor(p.row_ptr.begin(), p.row_ptr.end() - 1);
+    std::vector<uint32_t> cursor(nv, 0);        // next row position j of every sorted slot
     for (uint32_t s = 0; s < p.ns; ++s) {
         const uint32_t m = sb.slot_morph[s];
         for (uint32_t j = d.morph_offset[m]; j < d.morph_offset[m + 1]; ++j) {
-            const uint32_t at = cursor[gs_of[d.morph_index[j]]]++;
+            const uint32_t g = gs_of[d.morph_index[j]];
+            const size_t at = size_t(p.ell[2 * size_t(g >> 6)]) + size_t(cursor[g]++) * 64 + (g & 63);
+            ++p.ne_real;
             const float *o = d.morph_value + 3 * size_t(j);
             for (int c = 0; c < 3; ++c) {
                 uint32_t bits;
@@ -314,11 +352,11 @@ mmdx_status build_plan(const mmdx_model_desc &d, Plan &p, std::string &err) {
                     p.finite_offsets = false;
             }
             if (p.f16) {
-                uint16_t *e = p.entries16.data() + 4 * size_t(at);
+                uint16_t *e = p.entries16.data() + 4 * at;
                 e[0] = f32_to_f16_rne(o[0]); e[1] = f32_to_f16_rne(o[1]); e[2] = f32_to_f16_rne(o[2]);
                 e[3] = uint16_t(s);
             } else {
-                float *e = p.entries.data() + 4 * size_t(at);
+                float *e = p.entries.data() + 4 * at;
                 e[0] = o[0]; e[1] = o[1]; e[2] = o[2];
                 std::memcpy(e + 3, &s, 4);
             }

@@ -12,7 +12,8 @@
 //   * per-class skin streams in minimal encodings (BDEF1: one u16; BDEF2: 2 x u16 + f32;
 //     BDEF4: 4 x u16 + 4 x f32); bone ids are TILE-LOCAL indices into the tile's sorted list of
 //     distinct bones, so a workgroup stages only the bones its tile uses into LDS.
-//   * the morph-major scatter lists turned into a vertex-major CSR gather whose per-vertex entry
+//   * the morph-major scatter lists turned into a vertex-major gather table (sliced ELL: 64 rows per
+//     slice, rows sorted by length inside a class so the padding is small) whose per-vertex entry
 //     order is the reference's accumulation order (morph index ascending, groups expanded
 //     depth-first in place, file order inside a morph): no atomics, bit-reproducible.
 #pragma once
@@ -29,6 +30,7 @@ namespace mmdx {
 #define MMDX_TILE 512
 #endif
 constexpr uint32_t kTileVerts = MMDX_TILE;  // vertices per tile = per workgroup
+constexpr uint32_t kSlicesPerTile = kTileVerts / 64;  // morph-table slices (wave-slots) per tile
 constexpr uint32_t kMaxGroupDepth = 64;   // group-morph nesting limit (cycles are rejected)
 
 struct TileHdr {                          // 48 bytes, read through the scalar cache
@@ -45,7 +47,8 @@ static_assert(sizeof(TileHdr) == 48, "TileHdr layout");
 struct Plan {
     uint32_t nv = 0, nb = 0, nm = 0, flags = 0;
     uint32_t ns = 0;          // slots (vertex-morph applications in traversal order)
-    uint32_t ne = 0;          // CSR entries
+    uint32_t ne = 0;          // morph-table entries incl. slice padding
+    uint32_t ne_real = 0;     // ... without padding (= vertex-morph entries after group expansion)
     uint32_t ntiles = 0;
     uint32_t n1 = 0, n2 = 0, n4 = 0;
     uint32_t max_tile_bones = 0;
@@ -70,8 +73,8 @@ struct Plan {
     std::vector<uint32_t> bone_list;  // tile-local -> global bone id
     std::vector<TileHdr> tiles;
 
-    // morph gather
-    std::vector<uint32_t> row_ptr;  // [NV+1], by sorted global slot
+    // morph gather: sliced ELL (see plan.cpp)
+    std::vector<uint32_t> ell;      // [ntiles*kSlicesPerTile][2] = {first entry, rows' padded length}
     std::vector<float> entries;     // [NE][4]  off.xyz, slot (as uint32 bits)     (f32 mode)
     std::vector<uint16_t> entries16;  // [NE][4] off.xyz as binary16, slot as u16  (f16 mode)
     std::vector<uint32_t> slot_top;   // [NS] top-level morph whose rate starts the chain
@@ -84,7 +87,7 @@ mmdx_status build_plan(const mmdx_model_desc &desc, Plan &plan, std::string &err
 
 // One frame's slot weights, following Poser::UpdateMorphTransform (L/motion/poser_impl.inl:328-339):
 // w = rate[top]; skip if w < 1e-7 (double compare); for each nested group: w = sub_rate * w, skip test
-// again.  A skipped slot gets 0.0f (the device skips w < 1e-7f).
+// again.  A skipped slot gets 0.0f (the device skips w < 1e-7f).  `out` has ns entries.
 void flatten_slot_weights(const Plan &plan, const float *rates, float *out);
 
 uint16_t f32_to_f16_rne(float f);

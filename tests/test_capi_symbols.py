@@ -43,7 +43,7 @@ def test_struct_sizes_match_header():
     # 64-bit layout computed by hand from the header: 6 x u32 + 12 pointers; 4 x u32 + 4 ptr + f32 + u32
     assert C.sizeof(_capi.ModelDesc) == 6 * 4 + 12 * 8
     assert C.sizeof(_capi.DeformArgs) == 4 * 4 + 4 * 8 + 8
-    assert C.sizeof(_capi.ModelInfo) == 12 * 4 + 8 + 8
+    assert C.sizeof(_capi.ModelInfo) == 80   # 13 u32, pad to 8, u64, 3 u32, tail pad
 
 
 def test_abi_version_and_error_string(hip_lib):

@@ -60,5 +60,15 @@ int main(int argc, char **argv) {
                    tv, group, ntiles * (ni / group), t00 * 1e3, bytes / (t00 * 1e-3) / 1e9, t01 * 1e3, t10 * 1e3, t11 * 1e3, i00 * 1e3, bytes / (i00 * 1e-3) / 1e9, i10 * 1e3);
         }
     }
+    {   // single-array variants: only A (12 B/vertex pieces), and one interleaved 32 B/vertex array
+        const int tv = 512, group = 16; int ntiles = int(nv / tv);
+        int piece4 = tv * 12 / 16;
+        float t = timeit([&] { deformlike<0, 0><<<dim3(ntiles, ni / group), 256>>>(a, a, ntiles, ni, group, piece4 / 2, nv * 12 / 16); });
+        printf("single array, 3 KB+3 KB pieces both into A                 %7.1f us %7.0f GB/s\n", t * 1e3, 2.0 * ni * ntiles * (piece4 / 2) * 16 / (t * 1e-3) / 1e9);
+        int p32 = tv * 32 / 16 / 2;   // deformlike writes 2*piece4 per instance: use halves of one 16 KB piece
+        float4 *c; CK(hipMalloc(&c, size_t(ni) * nv * 32 + (4 << 20)));
+        float t2 = timeit([&] { deformlike<0, 0><<<dim3(ntiles, ni / group), 256>>>(c, c + p32, ntiles, ni, group, p32, nv * 32 / 16); });
+        printf("vertex32-like: one array, 16 KB pieces, stride nv*32        %7.1f us %7.0f GB/s\n", t2 * 1e3, 2.0 * ni * ntiles * p32 * 16 / (t2 * 1e-3) / 1e9);
+    }
     return 0;
 }
