@@ -187,6 +187,72 @@ def test_nonfinite_morph_offsets_keep_skip_semantics(oracle):
         assert np.isfinite(pos[0]).all() and not np.isfinite(pos[1]).all() and np.isnan(pos[2]).any()
 
 
+def _random_model(rng):
+    nv = int(rng.choice([1, 3, 65, 300, 777, 1500, 2600, 5200]))
+    nb = int(rng.choice([1, 2, 9, 40, 130, 600]))
+    mix = rng.dirichlet([0.6, 1.0, 0.8, 0.3])
+    m = synth.make_model(nv, nb, 1, 1, seed=int(rng.randint(1 << 30)), mix=tuple(mix),
+                         window=int(rng.choice([1, 4, 16, 64, 1024])))
+    # random morph table: vertex morphs (with duplicates), groups (depth <= 2), ignored types
+    n_vm = int(rng.randint(0, 7))
+    types, off, idx, val = [], [0], [], []
+    for _ in range(n_vm):
+        k = int(rng.randint(0, min(nv, 60) + 1))
+        types.append(MORPH_VERTEX)
+        idx += list(rng.randint(0, nv, k))
+        val += list(rng.uniform(-0.5, 0.5, (k, 3)))
+        off.append(len(idx))
+    n_extra = int(rng.randint(0, 4)) if n_vm else 0
+    for e in range(n_extra):
+        kind = rng.choice(["group", "bone", "uv"])
+        if kind == "group":
+            members = rng.randint(0, len(types), int(rng.randint(1, 4)))   # may reference earlier groups
+            types.append(MORPH_GROUP)
+            for mm in members:
+                idx.append(int(mm))
+                val.append((float(rng.choice([0.5, 1.0, 2.0, 1e-4, -1.0])), 0.0, 0.0))
+        else:
+            types.append(2 if kind == "bone" else 3)
+            idx.append(0)
+            val.append((0.1, 0.2, 0.3))
+        off.append(len(idx))
+    m.morph_type = np.asarray(types, np.int32)
+    m.morph_off = np.asarray(off, np.uint32)
+    m.morph_index = np.asarray(idx, np.uint32).reshape(-1)
+    m.morph_value = np.asarray(val, np.float32).reshape(-1, 3)
+    m.bone_weights[rng.randint(0, nv, max(1, nv // 8)), 0] = rng.choice([0.0, 1.0, 5e-8, 0.9999999])
+    return m
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_models_all_call_forms(oracle, seed):
+    """Random sizes / class mixes / bone windows / morph tables (duplicates, groups of groups, ignored
+    types) through every call form: single, batched per-instance, batched shared, vertex32."""
+    rng = np.random.RandomState(9000 + seed)
+    m = _random_model(rng)
+    ni = int(rng.choice([1, 2, 5, 9, 33]))
+    normalize = bool(rng.randint(2))
+    rates = rng.choice([0.0, 1.0, 0.3, -0.2, 5e-8, 2.5], size=(ni, m.nm)).astype(np.float32)
+    pals = synth.make_palettes(m, rng.randint(0, 500, ni))
+    skin = oracle.normalize(m) if normalize else None
+    with DeformModel(m, normalize=normalize) as dm:
+        pos, nrm = dm.deform_batched(rates, pals)
+        v32 = dm.deform_batched(rates, pals, layout=api.OUT_VERTEX32, pos_scale=0.1)
+        spos, snrm = dm.deform_batched(rates[0], pals, shared_weights=True)
+        for i in range(ni):
+            ep, en = oracle.skin(m, pals[i], oracle.morph(m, rates[i]), skin)
+            gu.assert_bits_equal(pos[i], ep, f"seed {seed} inst {i} pos")
+            gu.assert_bits_equal(nrm[i], en, f"seed {seed} inst {i} nrm")
+            gu.assert_bits_equal(v32[i], oracle.repack32(m, ep, en, 0.1), f"seed {seed} inst {i} v32")
+            sp, sn = oracle.skin(m, pals[i], oracle.morph(m, rates[0]), skin)
+            gu.assert_bits_equal(spos[i], sp, f"seed {seed} shared inst {i} pos")
+            gu.assert_bits_equal(snrm[i], sn, f"seed {seed} shared inst {i} nrm")
+        p1, n1 = dm.deform(rates[ni - 1], pals[ni - 1])
+        ep, en = oracle.skin(m, pals[ni - 1], oracle.morph(m, rates[ni - 1]), skin)
+        gu.assert_bits_equal(p1, ep, "single pos")
+        gu.assert_bits_equal(n1, en, "single nrm")
+
+
 def test_device_resident_io_matches_host_io(oracle):
     """The bench path: palettes, weights and outputs all resident in HBM."""
     m = synth.make_model(5000, 120, 10, 400, seed=31)

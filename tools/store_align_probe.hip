@@ -53,6 +53,9 @@ int main() {
     run("stride 655360 = 640 KiB", 0, gib, 655360);
     run("stride 1 MiB", 0, gib + (256 << 20), 1 << 20);
     run("repeat: B = A + 1 GiB", 0, gib, 600000);
+    run("INSTANCE-MAJOR: B_i right after A_i (stride 1.2 MB)", 0, 600000, 1200000);
+    run("INSTANCE-MAJOR +4 KiB gap (stride 1.2 MB + 8 KiB)", 0, 600000 + 4096, 1200000 + 8192);
+    run("repeat: B = A + 1 GiB", 0, gib, 600000);
     for (int i = 0; i < 4; ++i) {      // fresh allocations, as the bench does
         char *pa, *pb; CK(hipMalloc(&pa, arr)); CK(hipMalloc(&pb, arr));
         float ms = timeit([&] { deformlike<<<dim3(ntiles, ni / group), 256>>>((float4 *)pa, (float4 *)pb, ni, group, piece4, 600000 / 16); });
