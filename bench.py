@@ -263,6 +263,71 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     for b in (d_pal, d_w, d_a, d_b):
         b.free()
 
+    # config 1: 20k verts / 150 bones / 30 morphs, 600 frames -- the reference's own CPU-runnable case.
+    # GPU: the 600 frames as 6 batched calls of 100 (per-frame morph weights, fused gather), interleaved
+    # 32-byte output incl. the 0.1 scale = Deform + UpdateDeformedVertices.  CPU: libmmd's whole frame
+    # (ResetPosing, SetMorphPose x NM, Pre/PostPhysicsPosing, Deform, repack) and the C restatement.
+    m1 = synth.make_config("config1_20k")
+    dm1 = DeformModel(m1)
+    fr = np.arange(600)
+    pals1, rates1 = synth.make_palettes(m1, fr), synth.morph_weights(m1.nm, fr)
+    d_pal, d_w = DeviceBuffer.from_numpy(pals1), DeviceBuffer.from_numpy(rates1)
+    sa, _ = dm1.out_sizes(api.OUT_VERTEX32, 100)
+    d_a = DeviceBuffer(sa)
+
+    def frames600():
+        for b in range(6):
+            dm1.deform_batched_raw(100, d_w.ptr + b * 100 * m1.nm * 4, d_pal.ptr + b * 100 * m1.nb * 64,
+                                   d_a.ptr, None, api.OUT_VERTEX32, flags_dev, 0.1)
+    ms600 = time_calls(dm1, frames600, 10)
+    c1 = {"gpu_ms_per_600_frames": ms600, "gpu_vertices_per_s": 600 * m1.nv / (ms600 * 1e-3)}
+    try:
+        from oracle.pyoracle import Oracle, Reference, reference_available   # checker, CPU leg only
+        import time as _t
+        orc = Oracle()
+        skin = orc.normalize(m1)
+        t0 = _t.perf_counter()
+        for f in range(600):
+            pos, nrm = orc.skin(m1, pals1[f], orc.morph(m1, rates1[f]), skin)
+            orc.repack32(m1, pos, nrm, 0.1)
+        c1["cpu_port_vertices_per_s"] = 600 * m1.nv / (_t.perf_counter() - t0)
+        if reference_available():
+            ref = Reference(m1, normalize=True)
+            c1["cpu_reference_vertices_per_s"] = 600 * m1.nv / ref.time_frames(rates1, pals1)
+            ref.close()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        c1["cpu_error"] = repr(e)
+    out["config1_600_frames"] = c1
+    for b in (d_pal, d_w, d_a):
+        b.free()
+    dm1.close()
+
+    # PMX loader (the first "next" row): the config-1 model written as a PMX 2.0 file, parsed by this
+    # repo's loader (C++, csrc/pmx.cpp) and by the reference's FileReader + PmxReader -- host CPU both.
+    try:
+        import tempfile
+        import time as _t
+        from simple_mmd_renderer_amd import pmx as pmxmod
+        data = pmxmod.write_pmx(m1)
+        path = os.path.join(tempfile.mkdtemp(prefix="mmdx_"), "config1.pmx")
+        open(path, "wb").write(data)
+        import ctypes as C
+        reps = 20
+        t0 = _t.perf_counter()
+        for _ in range(reps):
+            h = C.c_void_p()
+            api.check(api.lib().mmdx_pmx_load_file(path.encode(), C.byref(h)))
+            api.lib().mmdx_pmx_destroy(h)
+        ours = (_t.perf_counter() - t0) / reps
+        c = {"file_MB": len(data) / 1e6, "mmdx_ms": ours * 1e3, "mmdx_MBps": len(data) / 1e6 / ours}
+        from oracle.pyoracle import Reference, reference_available
+        if reference_available():
+            ref_s = Reference.time_pmx_load(path, reps)
+            c.update({"reference_ms": ref_s * 1e3, "reference_MBps": len(data) / 1e6 / ref_s})
+        out["pmx_loader_config1_file"] = c
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["pmx_loader_config1_file"] = {"error": repr(e)}
+
     # config 5: 262 144 verts, 512 bones, 1024 morphs x 4096 entries, fp16 positions
     m5 = synth.make_config("config5_256k")
     dm5 = DeformModel(m5, f16_positions=True)

@@ -220,6 +220,51 @@ MMDX_API mmdx_status mmdx_bench_store_pattern(void *out_a_device, void *out_b_de
                                               uint32_t n_vertices, uint32_t n_instances,
                                               int32_t iterations, float *avg_ms);
 
+/* ---- PMX 2.0 loader (the data format on the input side of the path) --------------------------- */
+/* From-scratch parser for the fields the deformation path consumes; replaces, for those fields,
+ * PmxReader::ReadModel (L/reader/pmx_reader_impl.inl:16-449) + FileReader (L/util/dwarf_impl.inl:29-130)
+ * with the same observable semantics (1/2-byte indices zero-extended, 4-byte sign-extended; UTF-16LE
+ * or UTF-8 text; unknown deform / morph types are errors).  Display frames, rigid bodies and joints
+ * are not read. */
+typedef struct mmdx_pmx_s *mmdx_pmx_t;
+
+typedef struct mmdx_pmx_info {
+    uint32_t struct_size;
+    uint32_t n_vertices, n_indices, n_textures, n_materials, n_bones, n_morphs, n_morph_entries;
+    uint32_t extra_uv;        /* additional UV sets per vertex (skipped)                            */
+    uint32_t utf8;            /* text encoding of the file: 1 = UTF-8, 0 = UTF-16LE                 */
+    uint8_t index_width[8];   /* vertex, texture, material, bone, morph, rigid body; 2 spare        */
+    uint64_t bytes_consumed;  /* file offset just behind the morph block                           */
+} mmdx_pmx_info;
+
+typedef struct mmdx_pmx_arrays {      /* pointers into the parsed model, valid until destroy       */
+    uint32_t struct_size;
+    uint32_t reserved0;
+    const uint32_t *triangles;             /* [n_indices] original winding                         */
+    const uint32_t *material_index_count;  /* [n_materials] consecutive index ranges               */
+    const float *bone_rest_position;       /* [n_bones][3]                                         */
+    const int32_t *bone_parent;            /* [n_bones], -1 = none                                 */
+    const int32_t *bone_transform_level;   /* [n_bones]                                            */
+    const uint16_t *bone_flags;            /* [n_bones] raw PMX bone flag word                     */
+    const uint8_t *morph_panel;            /* [n_morphs]                                           */
+    const float *edge_scale;               /* [n_vertices]                                         */
+} mmdx_pmx_arrays;
+
+enum { MMDX_PMX_NAME_MODEL = 0, MMDX_PMX_NAME_BONE = 1, MMDX_PMX_NAME_MORPH = 2,
+       MMDX_PMX_NAME_MATERIAL = 3, MMDX_PMX_NAME_TEXTURE = 4 };
+
+MMDX_API mmdx_status mmdx_pmx_parse(const void *data, size_t size, mmdx_pmx_t *out_pmx);
+MMDX_API mmdx_status mmdx_pmx_load_file(const char *path, mmdx_pmx_t *out_pmx);
+MMDX_API void mmdx_pmx_destroy(mmdx_pmx_t pmx);
+MMDX_API mmdx_status mmdx_pmx_get_info(mmdx_pmx_t pmx, mmdx_pmx_info *info);
+/* Fills `desc` with pointers into `pmx` (valid until mmdx_pmx_destroy) and MMDX_CREATE_NORMALIZE,
+ * ready for mmdx_model_create(): the reference's reader ends with model.Normalize() too. */
+MMDX_API mmdx_status mmdx_pmx_get_model_desc(mmdx_pmx_t pmx, mmdx_model_desc *desc);
+MMDX_API mmdx_status mmdx_pmx_get_arrays(mmdx_pmx_t pmx, mmdx_pmx_arrays *arrays);
+/* Names as UTF-8 (bone and morph names are what VMD motion data is keyed by). */
+MMDX_API mmdx_status mmdx_pmx_get_name(mmdx_pmx_t pmx, int32_t kind, uint32_t index, char *buf,
+                                       size_t buf_size);
+
 #ifdef __cplusplus
 }
 #endif

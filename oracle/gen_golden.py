@@ -267,6 +267,32 @@ def main():
     set_morphs(m, [(MORPH_VERTEX, [(int(v), (1e-39, -2e-39, 3e-20)) for v in range(0, m.nv, 2)])])
     save("g14_denormals", m, run_reference(m, np.array([[1.0], [1e-3]], F32), pal))
 
+    # PMX loader fixture: a small .pmx written by simple_mmd_renderer_amd.pmx.write_pmx, and what
+    # the reference made of it (FileReader + PmxReader::ReadModel + Normalize + Poser).
+    from simple_mmd_renderer_amd import pmx as pmxmod
+    m = synth.make_model(600, 24, 5, 80, 113)
+    m.bone_weights[::9, 0] = 0.0
+    m.bone_weights[4::13, 0] = 1.0
+    # 4 additional UV sets: the reference's reader dereferences a null proxy for 1..3 of them
+    # (missing breaks in Vertex::SetExtraUVCoordinate, L/model/model_vertex_impl.inl:105-116)
+    data = pmxmod.write_pmx(m, pmxmod.PmxWriteOptions(extra_uv=4))
+    ppath = os.path.join(OUT, "pmx_small.pmx")
+    open(ppath, "wb").write(data)
+    ref = Reference.from_pmx(ppath)
+    t, _, _ = ref.get_skin()
+    fr = [2, 31, 77]
+    rates = synth.morph_weights(m.nm, fr)
+    pals = synth.make_palettes(m, fr)
+    pos, nrm, v32 = [], [], []
+    for f in range(len(fr)):
+        p_, n_, _ = ref.run(rates[f], pals[f])
+        pos.append(p_); nrm.append(n_); v32.append(ref.repack32(0.1))
+    ref.close()
+    np.savez_compressed(os.path.join(OUT, "pmx_small_expect.npz"), rates=rates, palette=pals,
+                        expect_pos=np.stack(pos), expect_nrm=np.stack(nrm), expect_v32=np.stack(v32),
+                        norm_type=t)
+    print(f"{'pmx_small.pmx':28s} {len(data) / 1024:7.1f} KB + expectations")
+
     # G13 config-1 plumbing: 20 000 verts / 150 bones / 30 morphs / 600 frames, checksums only.
     cfg = synth.CONFIGS["config1_20k"]
     m = synth.make_config("config1_20k")

@@ -147,6 +147,38 @@ class Reference:
             _p(k[8], C.c_int64), _p(k[9], C.c_int32), _p(k[10], C.c_uint32), _p(k[11], C.c_uint32),
             _p(k[12], C.c_float), C.c_int(1 if normalize else 0)))
 
+    @classmethod
+    def from_pmx(cls, path: str) -> "Reference":
+        """Load a .pmx through the reference's own FileReader + PmxReader (+ Normalize) + Poser."""
+        if not reference_available():
+            raise RuntimeError("oracle/_ref/libmmd_ref.so not built (needs /root/reference)")
+        self = cls.__new__(cls)
+        lib = C.CDLL(REF_SO)
+        lib.mmdref_create_from_pmx.restype = C.c_void_p
+        lib.mmdref_last_error.restype = C.c_char_p
+        lib.mmdref_time_frames.restype = C.c_double
+        lib.mmdref_time_crowd.restype = C.c_double
+        lib.mmdref_time_pmx_load.restype = C.c_double
+        h = lib.mmdref_create_from_pmx(str(path).encode())
+        if not h:
+            raise RuntimeError("libmmd PmxReader: " + (lib.mmdref_last_error() or b"").decode("utf-8", "replace"))
+        self.lib, self.h = lib, C.c_void_p(h)
+        nv, nb, nm, nt = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib.mmdref_get_counts(self.h, C.byref(nv), C.byref(nb), C.byref(nm), C.byref(nt))
+
+        class _Dims:          # just enough of a FlatModel for the accessors below
+            pass
+        self.model = _Dims()
+        self.model.nv, self.model.nb, self.model.nm, self.model.ntri = nv.value, nb.value, nm.value, nt.value
+        self._keep = []
+        return self
+
+    @staticmethod
+    def time_pmx_load(path: str, repeats: int = 5) -> float:
+        lib = C.CDLL(REF_SO)
+        lib.mmdref_time_pmx_load.restype = C.c_double
+        return float(lib.mmdref_time_pmx_load(str(path).encode(), C.c_int(repeats))) / repeats
+
     def close(self):
         if self.h:
             self.lib.mmdref_destroy(self.h)

@@ -181,6 +181,45 @@ void *mmdref_create(uint32_t nv, uint32_t nb, uint32_t nm,
     return r;
 }
 
+// The reference's own loader: FileReader + PmxReader::ReadModel (which ends with model.Normalize()),
+// then Poser -- used to pin this repo's PMX parser by write -> read round trips.
+// Returns NULL (and the message through mmdref_last_error) when libmmd throws.
+static std::string g_ref_err;
+const char *mmdref_last_error(void) { return g_ref_err.c_str(); }
+
+void *mmdref_create_from_pmx(const char *path) {
+    Ref *r = new Ref;
+    try {
+        std::string p(path);
+        mmd::FileReader file(std::wstring(p.begin(), p.end()));
+        mmd::PmxReader(file).ReadModel(r->model);
+        r->poser = new mmd::Poser(r->model);
+    } catch (const std::exception &e) {
+        g_ref_err = e.what();
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+
+void mmdref_get_counts(void *h, uint32_t *nv, uint32_t *nb, uint32_t *nm, uint32_t *ntri) {
+    Ref *r = static_cast<Ref *>(h);
+    *nv = uint32_t(r->model.GetVertexNum()); *nb = uint32_t(r->model.GetBoneNum());
+    *nm = uint32_t(r->model.GetMorphNum()); *ntri = uint32_t(r->model.GetTriangleNum());
+}
+
+// Parse time of the reference's loader alone (seconds), for the loader's CPU baseline.
+double mmdref_time_pmx_load(const char *path, int repeats) {
+    std::string p(path);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < repeats; ++i) {
+        mmd::Model model;
+        mmd::FileReader file(std::wstring(p.begin(), p.end()));
+        mmd::PmxReader(file).ReadModel(model);
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void mmdref_destroy(void *h) { delete static_cast<Ref *>(h); }
 
 // Skin tags after the optional Normalize() -- lets tests check the load-time retagging.

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/mmdx.h"
+#include "error.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
 
@@ -22,22 +23,16 @@ using namespace mmdx;
 
 namespace {
 
-thread_local std::string g_err;
 int g_device = 0;
 std::once_flag g_prepare_once[16];
 hipError_t g_prepare_status[16];
 
-mmdx_status fail(mmdx_status st, const std::string &msg) {
-    g_err = msg;
-    return st;
-}
-
 mmdx_status hip_fail(hipError_t e, const char *what) {
-    g_err = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
     // leave no sticky error behind for the next call
     (void)hipGetLastError();
-    return e == hipErrorOutOfMemory ? MMDX_ERR_OUT_OF_MEMORY
-                                    : (e == hipErrorNoDevice ? MMDX_ERR_NO_DEVICE : MMDX_ERR_HIP);
+    return fail(e == hipErrorOutOfMemory ? MMDX_ERR_OUT_OF_MEMORY
+                                         : (e == hipErrorNoDevice ? MMDX_ERR_NO_DEVICE : MMDX_ERR_HIP),
+                std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")");
 }
 
 #define HIP_TRY(expr)                                          \
@@ -157,8 +152,6 @@ size_t out_bytes_b(uint32_t layout, uint64_t nvi) {
 extern "C" {
 
 uint32_t mmdx_abi_version(void) { return MMDX_ABI_VERSION; }
-
-const char *mmdx_last_error_string(void) { return g_err.c_str(); }
 
 mmdx_status mmdx_device_count(int32_t *count) {
     if (!count) return fail(MMDX_ERR_INVALID_ARGUMENT, "count is NULL");

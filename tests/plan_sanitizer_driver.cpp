@@ -59,5 +59,54 @@ int main() {
             if (t.n1 + t.n2 > t.nv || t.bone_off + t.nbt > plan.bone_list.size()) { std::printf("bad tile\n"); return 2; }
     }
     std::printf("built=%d rejected=%d\n", built, rejected);
-    return built > 30 ? 0 : 3;
+    if (built <= 30) return 3;
+
+    // PMX parser under the sanitizers: a minimal valid file, then byte-level fuzzing of it (every
+    // outcome must be "parsed" or "rejected", never an out-of-bounds read)
+    std::vector<uint8_t> f;
+    auto put = [&](const void *p, size_t n) { f.insert(f.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    auto i32 = [&](int32_t v) { put(&v, 4); };
+    auto f32 = [&](float v) { put(&v, 4); };
+    auto text = [&](const char *s) { i32(int32_t(std::strlen(s))); put(s, std::strlen(s)); };
+    put("PMX ", 4); f32(2.0f);
+    const uint8_t globals[9] = {8, 1, 0, 1, 1, 1, 1, 1, 1};
+    put(globals, 9);
+    text("m"); text("m"); text(""); text("");
+    i32(3);
+    for (int v = 0; v < 3; ++v) {
+        for (int k = 0; k < 8; ++k) f32(float(v + k));
+        const uint8_t t = uint8_t(v == 2 ? 2 : v);
+        put(&t, 1);
+        const uint8_t b[4] = {0, 1, 0, 1};
+        if (t == 0) put(b, 1);
+        else if (t == 1) { put(b, 2); f32(0.5f); }
+        else { put(b, 4); for (int k = 0; k < 4; ++k) f32(0.25f); }
+        f32(1.0f);
+    }
+    i32(3); const uint8_t tri[3] = {0, 1, 2}; put(tri, 3);
+    i32(0); i32(0);                                  // textures, materials
+    i32(2);                                          // bones
+    for (int b = 0; b < 2; ++b) {
+        text("b"); text("b"); f32(0); f32(float(b)); f32(0);
+        const uint8_t parent = b ? 0 : 255; put(&parent, 1);
+        i32(0); const uint16_t flags = 0x001f; put(&flags, 2);
+        const uint8_t child = 1; put(&child, 1);
+    }
+    i32(1);                                          // one vertex morph
+    text("mm"); text("mm"); const uint8_t pt[2] = {1, 1}; put(pt, 2); i32(1);
+    const uint8_t vi = 2; put(&vi, 1); f32(0.1f); f32(0.2f); f32(0.3f);
+    mmdx_pmx_t pmx = nullptr;
+    if (mmdx_pmx_parse(f.data(), f.size(), &pmx) != MMDX_OK) { std::printf("valid pmx rejected: %s\n", mmdx_last_error_string()); return 4; }
+    mmdx_pmx_destroy(pmx);
+    int ok = 0, bad = 0;
+    for (int it = 0; it < 4000; ++it) {
+        std::vector<uint8_t> g = f;
+        const int nmut = 1 + int(rng() % 4);
+        for (int k = 0; k < nmut; ++k) g[rng() % g.size()] = uint8_t(rng());
+        if (it % 7 == 0) g.resize(rng() % g.size());
+        pmx = nullptr;
+        if (mmdx_pmx_parse(g.data(), g.size(), &pmx) == MMDX_OK) { ++ok; mmdx_pmx_destroy(pmx); } else ++bad;
+    }
+    std::printf("pmx fuzz: parsed=%d rejected=%d\n", ok, bad);
+    return 0;
 }

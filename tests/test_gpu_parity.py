@@ -396,3 +396,22 @@ def test_cpp_host_mirror_frame_loop():
     assert "frames=30 nv=20000" in r.stdout and "MISMATCH" not in r.stdout
     again = subprocess.run([exe, "20000", "30"], capture_output=True, text=True, timeout=120)
     assert again.stdout == r.stdout            # deterministic, run to run
+
+
+def test_pmx_file_to_gpu_end_to_end():
+    """tests/golden/pmx_small.pmx -> this repo's PMX loader -> mmdx_model_create -> deform, against what
+    libmmd (PmxReader + Normalize + Poser::Deform + repack) produced from the same file."""
+    import os
+    from simple_mmd_renderer_amd import pmx
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "pmx_small_expect.npz"))
+    pm = pmx.load_pmx(os.path.join(gu.GOLDEN_DIR, "pmx_small.pmx"))
+    with DeformModel(pm.flat, normalize=True) as dm:
+        t, _, _ = dm.get_skin()
+        want = z["norm_type"]
+        assert np.array_equal(np.where(t == 0, 0, np.where(t == 2, 2, 1)),
+                              np.where(want == 0, 0, np.where(want == 2, 2, 1)))
+        for f in range(z["rates"].shape[0]):
+            pos, nrm = dm.deform(z["rates"][f], z["palette"][f])
+            gu.assert_bits_equal(pos, z["expect_pos"][f], "pos")
+            gu.assert_bits_equal(nrm, z["expect_nrm"][f], "nrm")
+            gu.assert_bits_equal(dm.deform_vertex32(z["rates"][f], z["palette"][f], 0.1), z["expect_v32"][f], "v32")
