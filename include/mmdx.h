@@ -265,6 +265,59 @@ MMDX_API mmdx_status mmdx_pmx_get_arrays(mmdx_pmx_t pmx, mmdx_pmx_arrays *arrays
 MMDX_API mmdx_status mmdx_pmx_get_name(mmdx_pmx_t pmx, int32_t kind, uint32_t index, char *buf,
                                        size_t buf_size);
 
+/* ---- VMD motion loader + morph-rate evaluation on the device (the per-frame input side) --------- */
+/* Replaces, for morph tracks, VmdReader::ReadMotion (L/reader/vmd_reader_impl.inl:9-79),
+ * MotionPlayer's name mapping (L/motion/poser_impl.inl:522-537) and Motion::GetMorphPose
+ * (L/motion/motion_impl.inl:382-424): the rates a crowd needs -- [instances][morphs], every instance at
+ * its own frame -- are produced in HBM, ready for mmdx_deform_batched(MMDX_WEIGHTS_ON_DEVICE).  Bone
+ * keyframes are parsed and exposed raw for the host's bone solve. */
+typedef struct mmdx_vmd_s *mmdx_vmd_t;
+typedef struct mmdx_morph_motion_s *mmdx_morph_motion_t;
+
+typedef struct mmdx_vmd_info {
+    uint32_t struct_size;
+    uint32_t n_bone_records, n_morph_records; /* as stored in the file                              */
+    uint32_t n_bone_tracks, n_morph_tracks;   /* distinct names                                     */
+    uint32_t n_bone_keys, n_morph_keys;       /* after "last record for a (name, frame) wins"       */
+    uint32_t max_frame;
+    uint64_t bytes_consumed;                  /* camera / light / shadow sections follow; not read  */
+} mmdx_vmd_info;
+
+typedef struct mmdx_vmd_bone_key {            /* one 111-byte VMD bone record minus the name         */
+    uint32_t frame;
+    float translation[3];
+    float rotation[4];                        /* quaternion x, y, z, w                               */
+    int8_t interpolation[64];                 /* x, y, z, rotation: 16 bytes each, control points at
+                                                 [0],[4],[8],[12] in units of 1/127                  */
+} mmdx_vmd_bone_key;
+
+enum { MMDX_FRAMES_ON_DEVICE = 1u << 0 };     /* with MMDX_OUT_ON_DEVICE for mmdx_morph_motion_eval  */
+
+MMDX_API mmdx_status mmdx_vmd_parse(const void *data, size_t size, mmdx_vmd_t *out_vmd);
+MMDX_API mmdx_status mmdx_vmd_load_file(const char *path, mmdx_vmd_t *out_vmd);
+MMDX_API void mmdx_vmd_destroy(mmdx_vmd_t vmd);
+MMDX_API mmdx_status mmdx_vmd_get_info(mmdx_vmd_t vmd, mmdx_vmd_info *info);
+MMDX_API mmdx_status mmdx_vmd_track_name(mmdx_vmd_t vmd, int32_t is_morph, uint32_t track, char *buf,
+                                         size_t buf_size);   /* UTF-8 */
+MMDX_API mmdx_status mmdx_vmd_bone_track(mmdx_vmd_t vmd, uint32_t track, const mmdx_vmd_bone_key **keys,
+                                         uint32_t *n_keys);  /* sorted by frame */
+MMDX_API mmdx_status mmdx_vmd_morph_track(mmdx_vmd_t vmd, uint32_t track, const uint32_t **frames,
+                                          const float **weights, uint32_t *n_keys);
+/* Associate the motion's morph tracks with a model's morphs by name (UTF-8, e.g. from
+ * mmdx_pmx_get_name); morphs without a track evaluate to 0. */
+MMDX_API mmdx_status mmdx_vmd_bind_morphs(mmdx_vmd_t vmd, uint32_t n_morphs,
+                                          const char *const *morph_names_utf8,
+                                          mmdx_morph_motion_t *out_motion);
+MMDX_API mmdx_status mmdx_morph_motion_get_info(mmdx_morph_motion_t motion, uint32_t *n_morphs,
+                                                uint32_t *n_mapped, uint32_t *n_keys);
+/* out_weights[i][m] = rate of model morph m at frames[i], i < n_instances.  Runs on `model`'s device
+ * and stream when `model` is given (so a following mmdx_deform_batched sees the result), else on the
+ * selected device's default stream.  flags: MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE. */
+MMDX_API mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t motion, mmdx_model_t model,
+                                            uint32_t n_instances, const uint32_t *frames,
+                                            uint32_t flags, float *out_weights);
+MMDX_API void mmdx_morph_motion_destroy(mmdx_morph_motion_t motion);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,6 +293,35 @@ def main():
                         norm_type=t)
     print(f"{'pmx_small.pmx':28s} {len(data) / 1024:7.1f} KB + expectations")
 
+    # VMD fixture: a small motion written by simple_mmd_renderer_amd.vmd.write_vmd and the morph rates
+    # libmmd's VmdReader + Motion::GetMorphPose give for it (per model morph, in model order).
+    from simple_mmd_renderer_amd import vmd as vmdmod
+    from oracle.pyoracle import ReferenceMotion
+    vnames = ["あ", "にこり", "まばたき", "ウィンク右", "MorphEN"]
+    vrng = np.random.RandomState(77)
+    mk = []
+    for n in vnames:
+        for f_ in sorted(vrng.choice(240, 8, replace=False)):
+            mk.append((n, int(f_), float(np.float32(vrng.uniform(-0.2, 1.2)))))
+    mk.append((vnames[2], mk[17][1], 0.625))
+    vrng.shuffle(mk)
+    vdata = vmdmod.write_vmd([("センター", 0, (0, 0, 0), (0, 0, 0, 1), None),
+                              ("センター", 45, (0, 1, 0), (0, 0, 0.3827, 0.9239), None)], mk)
+    vpath = os.path.join(OUT, "vmd_small.vmd")
+    open(vpath, "wb").write(vdata)
+    rmot = ReferenceMotion(vpath)
+    model_names = [vnames[3], "使われない", vnames[0], vnames[1], vnames[4], vnames[2]]   # model order != file order
+    at = np.r_[np.arange(0, 260), 100000].astype(np.uint32)
+    rates = np.zeros((at.size, len(model_names)), np.float32)
+    for j, n in enumerate(model_names):
+        for i, f_ in enumerate(at):
+            w_ = rmot.morph_weight(n.encode("shift_jis"), int(f_))
+            rates[i, j] = 0.0 if np.isnan(w_) else w_          # no track: the rate stays at ResetPosing's 0
+    rmot.close()
+    np.savez_compressed(os.path.join(OUT, "vmd_small_expect.npz"), frames=at, expect_rates=rates,
+                        model_morph_names=np.array(model_names))
+    print(f"{'vmd_small.vmd':28s} {len(vdata) / 1024:7.1f} KB + expectations")
+
     # G13 config-1 plumbing: 20 000 verts / 150 bones / 30 morphs / 600 frames, checksums only.
     cfg = synth.CONFIGS["config1_20k"]
     m = synth.make_config("config1_20k")

@@ -178,6 +178,40 @@ void mmdx_oracle_repack32(uint32_t nv, const float *pos, const float *nrm, const
     }
 }
 
+/* ---- VMD morph track evaluation (Motion::GetMorphPose, L/motion/motion_impl.inl:382-424) ------- */
+/* key_off[NM+1], frames/weights sorted ascending inside a morph; out[NI][NM].  A morph without keys
+ * keeps 0 (SeekFrame never touches it after ResetPosing, L/motion/poser_impl.inl:539-542, :131-133). */
+void mmdx_oracle_morph_tracks(uint32_t nm, const uint32_t *key_off, const uint32_t *frames,
+                              const float *weights, uint32_t ni, const uint32_t *at, float *out) {
+    for (uint32_t i = 0; i < ni; ++i) {
+        const uint32_t frame = at[i];
+        for (uint32_t m = 0; m < nm; ++m) {
+            const uint32_t b = key_off[m], e = key_off[m + 1];
+            float w = 0.0f;
+            if (e > b) {
+                if (frames[b] >= frame) {
+                    w = weights[b];
+                } else if (frames[e - 1] <= frame) {
+                    w = weights[e - 1];
+                } else {
+                    uint32_t r = b;
+                    while (frames[r] <= frame) ++r;      /* first key after `frame` (upper_bound) */
+                    const uint32_t l = r - 1;
+                    if (frames[l] == frame) {
+                        w = weights[l];
+                    } else {
+                        const float bary = (float)(frame - frames[l]) / (float)(frames[r] - frames[l]);
+                        const float a = weights[l] * (1 - bary);
+                        const float c = weights[r] * bary;
+                        w = a + c;
+                    }
+                }
+            }
+            out[(size_t)i * nm + m] = w;
+        }
+    }
+}
+
 /* ---- cpu_baseline timing helpers (kind "port"; seconds, single thread) ---------------------- */
 static double now_s(void) {
     struct timespec ts;

@@ -96,6 +96,20 @@ class Oracle:
         vimg = self.morph(model, rates)
         return self.skin(model, palette, vimg, skin)
 
+    def morph_tracks(self, key_off, frames, weights, at):
+        """Motion::GetMorphPose for every model morph at the frames `at` -> f32 [len(at), NM]."""
+        key_off = _c(key_off, np.uint32)
+        at = _c(at, np.uint32).reshape(-1)
+        nm = key_off.size - 1
+        out = np.zeros((at.size, nm), np.float32)
+        fr, w = _c(frames, np.uint32), _c(weights, np.float32)
+        if fr.size == 0:
+            fr, w = np.zeros(1, np.uint32), np.zeros(1, np.float32)
+        self.lib.mmdx_oracle_morph_tracks(C.c_uint32(nm), _p(key_off, C.c_uint32), _p(fr, C.c_uint32),
+                                          _p(w, C.c_float), C.c_uint32(at.size), _p(at, C.c_uint32),
+                                          _p(out, C.c_float))
+        return out
+
     def time_crowd(self, model, rates, palettes, normalize=True):
         """Seconds for one crowd step (shared morph pass + one skinning pass per palette)."""
         t, ids, w = self.normalize(model) if normalize else (
@@ -118,6 +132,36 @@ class Oracle:
 
 def reference_available() -> bool:
     return os.path.exists(REF_SO)
+
+
+class ReferenceMotion:
+    """libmmd's VmdReader + Motion (oracle/ref_harness.cpp)."""
+
+    def __init__(self, path: str):
+        if not reference_available():
+            raise RuntimeError("oracle/_ref/libmmd_ref.so not built (needs /root/reference)")
+        self.lib = C.CDLL(REF_SO)
+        self.lib.mmdref_motion_load.restype = C.c_void_p
+        self.lib.mmdref_last_error.restype = C.c_char_p
+        self.lib.mmdref_motion_morph_weight.restype = C.c_float
+        h = self.lib.mmdref_motion_load(str(path).encode())
+        if not h:
+            raise RuntimeError("libmmd VmdReader: " + (self.lib.mmdref_last_error() or b"").decode("utf-8", "replace"))
+        self.h = C.c_void_p(h)
+
+    def morph_weight(self, sjis_name: bytes, frame: int) -> float:
+        """Motion::GetMorphPose(name, frame) for the track whose Shift-JIS name bytes are given; NaN when
+        the motion has no such track."""
+        return float(self.lib.mmdref_motion_morph_weight(self.h, sjis_name, C.c_uint32(frame)))
+
+    def names_match_model(self, ref_model: "Reference") -> int:
+        """How many of the model's morph names libmmd finds in the motion (MotionPlayer's mapping)."""
+        return int(self.lib.mmdref_motion_count_registered_morphs(self.h, ref_model.h))
+
+    def close(self):
+        if self.h:
+            self.lib.mmdref_motion_destroy(self.h)
+            self.h = None
 
 
 class Reference:

@@ -22,6 +22,7 @@
 #include <mmd/mmd.hxx>
 
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -218,6 +219,41 @@ double mmdref_time_pmx_load(const char *path, int repeats) {
         mmd::PmxReader(file).ReadModel(model);
     }
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---- VMD: libmmd's own VmdReader + Motion --------------------------------------------------------
+void *mmdref_motion_load(const char *path) {
+    mmd::Motion *m = new mmd::Motion;
+    try {
+        std::string p(path);
+        mmd::FileReader file(std::wstring(p.begin(), p.end()));
+        mmd::VmdReader(file).ReadMotion(*m);
+    } catch (const std::exception &e) {
+        g_ref_err = e.what();
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+void mmdref_motion_destroy(void *h) { delete static_cast<mmd::Motion *>(h); }
+
+// Motion::GetMorphPose for the track stored under the given Shift-JIS name (converted exactly as the
+// reader converted it, byte-order mark and all); NaN if no such track.
+float mmdref_motion_morph_weight(void *h, const char *sjis_name, uint32_t frame) {
+    mmd::Motion *m = static_cast<mmd::Motion *>(h);
+    const std::wstring key = mmd::ShiftJISToUTF16String(std::string(sjis_name));
+    if (!m->IsMorphRegistered(key)) return std::nanf("");
+    return m->GetMorphPose(key, size_t(frame)).GetWeight();
+}
+
+// MotionPlayer's name association (poser_impl.inl:522-537), counted.
+uint32_t mmdref_motion_count_registered_morphs(void *motion, void *ref) {
+    mmd::Motion *m = static_cast<mmd::Motion *>(motion);
+    Ref *r = static_cast<Ref *>(ref);
+    uint32_t n = 0;
+    for (size_t i = 0; i < r->model.GetMorphNum(); ++i)
+        if (m->IsMorphRegistered(r->model.GetMorph(i).GetName())) ++n;
+    return n;
 }
 
 void mmdref_destroy(void *h) { delete static_cast<Ref *>(h); }

@@ -97,6 +97,17 @@ SIGNATURES = {
     "mmdx_pmx_get_model_desc": (C.c_int32, [C.c_void_p, C.POINTER(ModelDesc)]),
     "mmdx_pmx_get_arrays": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mmdx_pmx_get_name": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "mmdx_vmd_parse": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mmdx_vmd_load_file": (C.c_int32, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "mmdx_vmd_destroy": (None, [C.c_void_p]),
+    "mmdx_vmd_get_info": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "mmdx_vmd_track_name": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "mmdx_vmd_bone_track": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, _u32p]),
+    "mmdx_vmd_morph_track": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, _u32p]),
+    "mmdx_vmd_bind_morphs": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]),
+    "mmdx_morph_motion_get_info": (C.c_int32, [C.c_void_p, _u32p, _u32p, _u32p]),
+    "mmdx_morph_motion_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "mmdx_morph_motion_destroy": (None, [C.c_void_p]),
 }
 
 _lib = None

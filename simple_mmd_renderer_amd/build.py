@@ -16,8 +16,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdx.so")
-SOURCES = ["api.cpp", "kernels.hip", "plan.cpp", "pmx.cpp", "error.cpp"]
-HEADERS = ["kernels.hpp", "plan.hpp", "error.hpp", os.path.join("..", "..", "include", "mmdx.h")]
+SOURCES = ["api.cpp", "kernels.hip", "plan.cpp", "pmx.cpp", "vmd.cpp", "error.cpp"]
+HEADERS = ["kernels.hpp", "plan.hpp", "error.hpp", "vmd.hpp", os.path.join("..", "..", "include", "mmdx.h")]
 ARCH = "gfx950"
 
 

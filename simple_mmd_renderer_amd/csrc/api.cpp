@@ -149,6 +149,16 @@ size_t out_bytes_b(uint32_t layout, uint64_t nvi) {
 
 }  // namespace
 
+void mmdx::morph_motion_release_device(MorphMotionDevice &d) {
+    if (d.device >= 0) (void)hipSetDevice(d.device);
+    for (void **p : {&d.key_off, &d.frames, &d.weights, &d.frames_in, &d.out}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    d.frames_in_bytes = d.out_bytes = 0;
+    d.device = -1;
+}
+
 extern "C" {
 
 uint32_t mmdx_abi_version(void) { return MMDX_ABI_VERSION; }
@@ -523,6 +533,70 @@ mmdx_status mmdx_profile_collect(mmdx_model_t m, uint32_t *n_calls, float *skin_
     *skin_ms_total = float(skin);
     *morph_ms_total = float(morph);
     m->prof_calls = 0;
+    return MMDX_OK;
+}
+
+// ---- VMD morph motion: device-side evaluation ----------------------------------------------------
+mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, uint32_t n_instances,
+                                   const uint32_t *frames, uint32_t flags, float *out_weights) {
+    if (!mm || !frames || !out_weights || !n_instances)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
+    const MorphMotionHost h = morph_motion_host(mm);
+    MorphMotionDevice &d = morph_motion_device(mm);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MMDX_ERR_NO_DEVICE, "no HIP device available (morph tracks are evaluated on the GPU)");
+    const int device = model && model->device >= 0 ? model->device : g_device;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = model && model->device >= 0 ? model->stream : nullptr;
+    if (d.device != device) {
+        morph_motion_release_device(d);
+        HIP_TRY(hipMalloc(&d.key_off, (size_t(h.nm) + 1) * 4));
+        HIP_TRY(hipMalloc(&d.frames, std::max<size_t>(size_t(h.nkeys) * 4, 16)));
+        HIP_TRY(hipMalloc(&d.weights, std::max<size_t>(size_t(h.nkeys) * 4, 16)));
+        HIP_TRY(hipMemcpy(d.key_off, h.key_off, (size_t(h.nm) + 1) * 4, hipMemcpyHostToDevice));
+        if (h.nkeys) {
+            HIP_TRY(hipMemcpy(d.frames, h.frames, size_t(h.nkeys) * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d.weights, h.weights, size_t(h.nkeys) * 4, hipMemcpyHostToDevice));
+        }
+        d.device = device;
+    }
+    MorphTrackParams t;
+    t.key_off = static_cast<const uint32_t *>(d.key_off);
+    t.key_frames = static_cast<const uint32_t *>(d.frames);
+    t.key_weights = static_cast<const float *>(d.weights);
+    t.nm = h.nm; t.ni = n_instances;
+    if (flags & MMDX_FRAMES_ON_DEVICE) {
+        t.frames = frames;
+    } else {
+        if (d.frames_in_bytes < size_t(n_instances) * 4) {
+            if (d.frames_in) (void)hipFree(d.frames_in);
+            d.frames_in = nullptr; d.frames_in_bytes = 0;
+            HIP_TRY(hipMalloc(&d.frames_in, size_t(n_instances) * 4));
+            d.frames_in_bytes = size_t(n_instances) * 4;
+        }
+        HIP_TRY(hipMemcpyAsync(d.frames_in, frames, size_t(n_instances) * 4, hipMemcpyHostToDevice, st));
+        t.frames = static_cast<const uint32_t *>(d.frames_in);
+    }
+    const size_t out_bytes = size_t(n_instances) * h.nm * 4;
+    if (flags & MMDX_OUT_ON_DEVICE) {
+        t.out = out_weights;
+    } else {
+        if (d.out_bytes < out_bytes) {
+            if (d.out) (void)hipFree(d.out);
+            d.out = nullptr; d.out_bytes = 0;
+            HIP_TRY(hipMalloc(&d.out, std::max<size_t>(out_bytes, 16)));
+            d.out_bytes = std::max<size_t>(out_bytes, 16);
+        }
+        t.out = static_cast<float *>(d.out);
+    }
+    HIP_TRY(launch_morph_track_eval(t, st));
+    if (!(flags & MMDX_OUT_ON_DEVICE)) {
+        if (out_bytes) HIP_TRY(hipMemcpyAsync(out_weights, t.out, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else if (!(flags & MMDX_FRAMES_ON_DEVICE)) {
+        HIP_TRY(hipStreamSynchronize(st));   // borrowed host frames must be consumed before returning
+    }
     return MMDX_OK;
 }
 

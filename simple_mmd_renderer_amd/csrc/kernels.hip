@@ -612,6 +612,39 @@ __global__ __launch_bounds__(kThreads) void flatten_kernel(const FlattenParams f
     else f.out[idx] = out;
 }
 
+// ---- VMD morph tracks -> per-instance morph rates (Motion::GetMorphPose, motion_impl.inl:382-424) ---
+// One thread per (instance, model morph): clamp to the first / last key, exact hit, else the linear
+// blend l*(1-t) + r*t with t = float(frame-left)/float(right-left) (IEEE division: hipcc keeps f32
+// division correctly rounded by default).  A morph without a track keeps rate 0, as after ResetPosing.
+__global__ __launch_bounds__(kThreads) void morph_track_eval_kernel(const MorphTrackParams t) {
+    const size_t idx = size_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (idx >= size_t(t.ni) * t.nm) return;
+    const uint32_t i = uint32_t(idx / t.nm), m = uint32_t(idx - size_t(i) * t.nm);
+    const uint32_t b = t.key_off[m], e = t.key_off[m + 1], frame = t.frames[i];
+    float w = 0.f;
+    if (e > b) {
+        if (t.key_frames[b] >= frame) {
+            w = t.key_weights[b];
+        } else if (t.key_frames[e - 1] <= frame) {
+            w = t.key_weights[e - 1];
+        } else {
+            uint32_t lo = b, hi = e - 1;               // key_frames[lo] < frame < key_frames[hi]
+            while (hi - lo > 1) {                      // first key whose frame is > `frame`
+                const uint32_t mid = (lo + hi) / 2;
+                if (t.key_frames[mid] > frame) hi = mid; else lo = mid;
+            }
+            const uint32_t lf = t.key_frames[lo], rf = t.key_frames[hi];
+            if (lf == frame) {
+                w = t.key_weights[lo];
+            } else {
+                const float bary = float(frame - lf) / float(rf - lf);
+                w = t.key_weights[lo] * (1.0f - bary) + t.key_weights[hi] * bary;
+            }
+        }
+    }
+    t.out[idx] = w;
+}
+
 // ---- streaming copy / fill: the practical HBM ceiling printed next to the roofline ---------------
 // Every workgroup owns one contiguous 4 KiB chunk, workgroups in address order: the shape that
 // reached the highest store rate on MI355X in tools/bw_probe (a few-thousand-block grid-stride loop
@@ -739,6 +772,14 @@ hipError_t launch_flatten(const FlattenParams &f, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(flatten_kernel, dim3(uint32_t((n + kThreads - 1) / kThreads)), dim3(kThreads),
                        0, stream, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_morph_track_eval(const MorphTrackParams &t, hipStream_t stream) {
+    const size_t n = size_t(t.ni) * t.nm;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(morph_track_eval_kernel, dim3(uint32_t((n + kThreads - 1) / kThreads)), dim3(kThreads),
+                       0, stream, t);
     return hipGetLastError();
 }
 

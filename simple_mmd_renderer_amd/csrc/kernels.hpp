@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "plan.hpp"
+#include "vmd.hpp"
 
 namespace mmdx {
 
@@ -77,6 +78,7 @@ hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenPara
 constexpr uint32_t kMaxFusedSlots = 8192;
 hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, hipStream_t stream);
 hipError_t launch_flatten(const FlattenParams &p, hipStream_t stream);
+hipError_t launch_morph_track_eval(const MorphTrackParams &t, hipStream_t stream);
 hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream);
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
 hipError_t prepare_kernels();  // raise the dynamic-LDS limit of every deform variant (once)

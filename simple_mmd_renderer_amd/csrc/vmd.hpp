@@ -1,0 +1,38 @@
+// vmd.hpp -- glue between the VMD host code (vmd.cpp, no HIP) and the HIP side (api.cpp, kernels.hip).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/mmdx.h"
+
+namespace mmdx {
+
+struct MorphMotionHost {          // keyframes of every model morph, model-morph order
+    uint32_t nm;
+    const uint32_t *key_off;      // [nm+1]
+    const uint32_t *frames;       // [nkeys] ascending inside a morph
+    const float *weights;         // [nkeys]
+    uint32_t nkeys;
+};
+
+struct MorphMotionDevice {        // owned by api.cpp (hipMalloc / hipFree)
+    void *key_off = nullptr, *frames = nullptr, *weights = nullptr;
+    void *frames_in = nullptr, *out = nullptr;   // per-call scratch for host-pointer callers
+    size_t frames_in_bytes = 0, out_bytes = 0;
+    int device = -1;
+};
+
+const MorphMotionHost morph_motion_host(const mmdx_morph_motion_s *m);
+MorphMotionDevice &morph_motion_device(mmdx_morph_motion_s *m);
+void morph_motion_release_device(MorphMotionDevice &d);   // api.cpp
+
+struct MorphTrackParams {
+    const uint32_t *key_off, *key_frames;
+    const float *key_weights;
+    const uint32_t *frames;       // [ni] frame number of every instance
+    float *out;                   // [ni][nm]
+    uint32_t nm, ni;
+};
+
+}  // namespace mmdx

@@ -1,0 +1,153 @@
+"""VMD motion files: a writer for synthetic fixtures and the Python face of the C-ABI loader /
+device evaluator (csrc/vmd.cpp + morph_track_eval_kernel).
+
+File layout as the reference's reader consumes it (L/reader/vmd_reader_impl.inl:9-79,
+L/reader/interprete/vmd_types.inl:17-37): 50-byte header, u32 count + 111-byte bone records,
+u32 count + 23-byte morph records; names are Shift-JIS in 15-byte fields.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi as api
+
+MAGIC = b"Vocaloid Motion Data 0002"
+
+
+def _name15(name: str) -> bytes:
+    b = name.encode("shift_jis")
+    if len(b) > 15:
+        raise ValueError("VMD names are at most 15 bytes of Shift-JIS: %r" % name)
+    return b + b"\0" * (15 - len(b))
+
+
+def write_vmd(bone_keys: Sequence[tuple], morph_keys: Sequence[Tuple[str, int, float]],
+              model_name: str = "synthetic") -> bytes:
+    """bone_keys: (name, frame, (tx,ty,tz), (qx,qy,qz,qw), interpolation[64] or None);
+    morph_keys: (name, frame, weight).  Records are written in the given order (a later record for
+    the same (name, frame) wins, as in the reference)."""
+    out = bytearray()
+    out += MAGIC + b"\0" * (30 - len(MAGIC))
+    mn = model_name.encode("shift_jis")[:20]
+    out += mn + b"\0" * (20 - len(mn))
+    out += struct.pack("<I", len(bone_keys))
+    for name, frame, t, q, interp in bone_keys:
+        out += _name15(name) + struct.pack("<I", frame) + struct.pack("<3f", *t) + struct.pack("<4f", *q)
+        ip = bytes(interp) if interp is not None else bytes([20, 20, 0, 0, 20, 20, 20, 20, 107, 107, 107, 107,
+                                                               107, 107, 107, 107] * 4)
+        assert len(ip) == 64
+        out += ip
+    out += struct.pack("<I", len(morph_keys))
+    for name, frame, w in morph_keys:
+        out += _name15(name) + struct.pack("<I", frame) + np.float32(w).tobytes()
+    out += struct.pack("<I", 0) * 3        # camera, light, self-shadow sections: empty
+    return bytes(out)
+
+
+class VmdInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_bone_records", C.c_uint32), ("n_morph_records", C.c_uint32),
+                ("n_bone_tracks", C.c_uint32), ("n_morph_tracks", C.c_uint32), ("n_bone_keys", C.c_uint32),
+                ("n_morph_keys", C.c_uint32), ("max_frame", C.c_uint32), ("bytes_consumed", C.c_uint64)]
+
+
+class VmdBoneKey(C.Structure):
+    _fields_ = [("frame", C.c_uint32), ("translation", C.c_float * 3), ("rotation", C.c_float * 4),
+                ("interpolation", C.c_int8 * 64)]
+
+
+class Vmd:
+    """A parsed VMD motion (mmdx_vmd_t)."""
+
+    def __init__(self, source):
+        lib = api.lib()
+        self.h = C.c_void_p()
+        if isinstance(source, (bytes, bytearray)):
+            buf = (C.c_char * len(source)).from_buffer_copy(bytes(source))
+            api.check(lib.mmdx_vmd_parse(buf, len(source), C.byref(self.h)))
+        else:
+            api.check(lib.mmdx_vmd_load_file(str(source).encode("utf-8"), C.byref(self.h)))
+        info = VmdInfo()
+        info.struct_size = C.sizeof(VmdInfo)
+        api.check(lib.mmdx_vmd_get_info(self.h, C.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in VmdInfo._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            api.lib().mmdx_vmd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _name(self, is_morph: int, i: int) -> str:
+        buf = C.create_string_buffer(256)
+        api.check(api.lib().mmdx_vmd_track_name(self.h, is_morph, i, buf, 256))
+        return buf.value.decode("utf-8", "replace")
+
+    @property
+    def morph_track_names(self) -> List[str]:
+        return [self._name(1, i) for i in range(self.info["n_morph_tracks"])]
+
+    @property
+    def bone_track_names(self) -> List[str]:
+        return [self._name(0, i) for i in range(self.info["n_bone_tracks"])]
+
+    def morph_track(self, i: int) -> Tuple[np.ndarray, np.ndarray]:
+        fr, w, n = C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)(), C.c_uint32()
+        api.check(api.lib().mmdx_vmd_morph_track(self.h, i, C.byref(fr), C.byref(w), C.byref(n)))
+        k = n.value
+        return (np.ctypeslib.as_array(fr, (k,)).copy() if k else np.zeros(0, np.uint32),
+                np.ctypeslib.as_array(w, (k,)).copy() if k else np.zeros(0, np.float32))
+
+    def bone_track(self, i: int) -> List[dict]:
+        keys, n = C.POINTER(VmdBoneKey)(), C.c_uint32()
+        api.check(api.lib().mmdx_vmd_bone_track(self.h, i, C.byref(keys), C.byref(n)))
+        return [dict(frame=keys[j].frame, translation=tuple(keys[j].translation), rotation=tuple(keys[j].rotation),
+                     interpolation=bytes(bytearray(keys[j].interpolation))) for j in range(n.value)]
+
+    def bind_morphs(self, morph_names: Sequence[str]) -> "MorphMotion":
+        return MorphMotion(self, morph_names)
+
+
+class MorphMotion:
+    """Morph tracks of a motion bound to a model's morph list; evaluated on the GPU."""
+
+    def __init__(self, vmd: Vmd, morph_names: Sequence[str]):
+        enc = [n.encode("utf-8") for n in morph_names]
+        arr = (C.c_char_p * max(len(enc), 1))(*enc)
+        self.h = C.c_void_p()
+        api.check(api.lib().mmdx_vmd_bind_morphs(vmd.h, len(enc), arr, C.byref(self.h)))
+        nm, mapped, keys = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        api.check(api.lib().mmdx_morph_motion_get_info(self.h, C.byref(nm), C.byref(mapped), C.byref(keys)))
+        self.nm, self.n_mapped, self.n_keys = nm.value, mapped.value, keys.value
+
+    def eval(self, frames, model=None) -> np.ndarray:
+        """Host convenience: frames [NI] -> rates f32 [NI, NM] (device evaluation + D2H)."""
+        fr = np.ascontiguousarray(frames, np.uint32).reshape(-1)
+        out = np.empty((fr.size, self.nm), np.float32)
+        api.check(api.lib().mmdx_morph_motion_eval(self.h, model.h if model is not None else None, fr.size,
+                                                   fr.ctypes.data, 0, out.ctypes.data))
+        return out
+
+    def eval_device(self, n_instances: int, frames_ptr, out_ptr, model=None) -> None:
+        """frames u32[NI] and out f32[NI][NM] resident in HBM; asynchronous on the model's stream."""
+        api.check(api.lib().mmdx_morph_motion_eval(self.h, model.h if model is not None else None, n_instances,
+                                                   frames_ptr, 1 | api.OUT_ON_DEVICE, out_ptr))
+
+    def close(self):
+        if getattr(self, "h", None):
+            api.lib().mmdx_morph_motion_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -108,5 +108,50 @@ int main() {
         if (mmdx_pmx_parse(g.data(), g.size(), &pmx) == MMDX_OK) { ++ok; mmdx_pmx_destroy(pmx); } else ++bad;
     }
     std::printf("pmx fuzz: parsed=%d rejected=%d\n", ok, bad);
+
+    // VMD parser: a small valid motion, then the same byte-level fuzzing
+    std::vector<uint8_t> m(50, 0);
+    std::memcpy(m.data(), "Vocaloid Motion Data 0002", 25);
+    auto mput = [&](const void *p, size_t n) { m.insert(m.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    const uint32_t nbone = 2, nmorph = 5;
+    mput(&nbone, 4);
+    for (uint32_t b = 0; b < nbone; ++b) {
+        uint8_t rec[111] = {0};
+        std::memcpy(rec, "bone", 4);
+        const uint32_t fr = b * 10; std::memcpy(rec + 15, &fr, 4);
+        mput(rec, sizeof(rec));
+    }
+    mput(&nmorph, 4);
+    for (uint32_t k = 0; k < nmorph; ++k) {
+        uint8_t rec[23] = {0};
+        std::memcpy(rec, k % 2 ? "a" : "b", 1);
+        const uint32_t fr = k * 3; const float w = 0.25f * float(k);
+        std::memcpy(rec + 15, &fr, 4); std::memcpy(rec + 19, &w, 4);
+        mput(rec, sizeof(rec));
+    }
+    mmdx_vmd_t vmd = nullptr;
+    if (mmdx_vmd_parse(m.data(), m.size(), &vmd) != MMDX_OK) { std::printf("valid vmd rejected: %s\n", mmdx_last_error_string()); return 5; }
+    const char *names[3] = {"a", "zz", "b"};
+    mmdx_morph_motion_t mm = nullptr;
+    if (mmdx_vmd_bind_morphs(vmd, 3, names, &mm) != MMDX_OK) return 6;
+    uint32_t nmm = 0, mapped = 0, nkeys = 0;
+    mmdx_morph_motion_get_info(mm, &nmm, &mapped, &nkeys);
+    if (nmm != 3 || mapped != 2 || nkeys != 5) { std::printf("bind: %u %u %u\n", nmm, mapped, nkeys); return 7; }
+    mmdx_morph_motion_destroy(mm);
+    mmdx_vmd_destroy(vmd);
+    ok = bad = 0;
+    for (int it = 0; it < 4000; ++it) {
+        std::vector<uint8_t> g = m;
+        const int nmut = 1 + int(rng() % 4);
+        for (int k = 0; k < nmut; ++k) g[rng() % g.size()] = uint8_t(rng());
+        if (it % 7 == 0) g.resize(rng() % g.size());
+        vmd = nullptr;
+        if (mmdx_vmd_parse(g.data(), g.size(), &vmd) == MMDX_OK) { ++ok; mmdx_vmd_destroy(vmd); } else ++bad;
+    }
+    std::printf("vmd fuzz: parsed=%d rejected=%d\n", ok, bad);
     return 0;
 }
+
+// vmd.cpp hands device buffers back to api.cpp (HIP); nothing to release in this host-only build
+#include "../simple_mmd_renderer_amd/csrc/vmd.hpp"
+void mmdx::morph_motion_release_device(mmdx::MorphMotionDevice &) {}

@@ -415,3 +415,62 @@ def test_pmx_file_to_gpu_end_to_end():
             gu.assert_bits_equal(pos, z["expect_pos"][f], "pos")
             gu.assert_bits_equal(nrm, z["expect_nrm"][f], "nrm")
             gu.assert_bits_equal(dm.deform_vertex32(z["rates"][f], z["palette"][f], 0.1), z["expect_v32"][f], "v32")
+
+
+def test_vmd_morph_rates_on_device_golden():
+    """tests/golden/vmd_small.vmd -> device evaluation of every model morph at 261 frames, against
+    libmmd's Motion::GetMorphPose answers."""
+    import os
+    from simple_mmd_renderer_amd import vmd
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "vmd_small_expect.npz"))
+    v = vmd.Vmd(os.path.join(gu.GOLDEN_DIR, "vmd_small.vmd"))
+    mm = v.bind_morphs([str(n) for n in z["model_morph_names"]])
+    got = mm.eval(z["frames"])
+    gu.assert_bits_equal(got, z["expect_rates"], "rates")
+    mm.close()
+
+
+def test_vmd_to_crowd_end_to_end(oracle):
+    """PMX file + VMD file -> rates for a crowd evaluated in HBM (every instance at its own frame) ->
+    mmdx_deform_batched with device-resident weights; against the oracle per instance."""
+    import os
+    from simple_mmd_renderer_amd import pmx, vmd
+    pm = pmx.load_pmx(os.path.join(gu.GOLDEN_DIR, "pmx_small.pmx"))
+    m = pm.flat
+    rng = np.random.RandomState(5)
+    keys = []
+    for n in pm.morph_names:
+        for f in sorted(rng.choice(120, 5, replace=False)):
+            keys.append((n, int(f), float(np.float32(rng.uniform(0, 1)))))
+    v = vmd.Vmd(vmd.write_vmd([], keys))
+    mm = v.bind_morphs(pm.morph_names)
+    assert mm.n_mapped == m.nm
+    ni = 21
+    frames = (np.arange(ni) * 7 % 130).astype(np.uint32)
+    pals = synth.make_palettes(m, frames)
+    with DeformModel(m) as dm:
+        d_fr, d_pal = DeviceBuffer.from_numpy(frames), DeviceBuffer.from_numpy(pals)
+        d_w = DeviceBuffer(ni * m.nm * 4)
+        sa, sb = dm.out_sizes(api.OUT_SOA, ni)
+        d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+        mm.eval_device(ni, d_fr.ptr, d_w.ptr, model=dm)        # same stream as the deform that follows
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA,
+                              api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE)
+        dm.sync()
+        rates = d_w.download((ni, m.nm), np.float32)
+        pos = d_a.download((ni, m.nv, 3), np.float32)
+        nrm = d_b.download((ni, m.nv, 3), np.float32)
+        # rates: the oracle's restatement of GetMorphPose on the bound tracks
+        tracks = {n: v.morph_track(i) for i, n in enumerate(v.morph_track_names)}
+        off, fr, w = [0], [], []
+        for n in pm.morph_names:
+            fr += list(tracks[n][0]); w += list(tracks[n][1]); off.append(len(fr))
+        want = oracle.morph_tracks(np.asarray(off, np.uint32), np.asarray(fr, np.uint32), np.asarray(w, np.float32), frames)
+        gu.assert_bits_equal(rates, want, "rates")
+        for i in range(ni):
+            ep, en = oracle_expect(oracle, m, want[i], pals[i])
+            gu.assert_bits_equal(pos[i], ep, f"inst {i} pos")
+            gu.assert_bits_equal(nrm[i], en, f"inst {i} nrm")
+        for b in (d_fr, d_pal, d_w, d_a, d_b):
+            b.free()
+    mm.close()

@@ -16,6 +16,7 @@ def test_plan_builder_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-std=c++17"] + SAN + [os.path.join(ROOT, "tests", "plan_sanitizer_driver.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "plan.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "pmx.cpp"),
+                                         os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "vmd.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "error.cpp"),
                                          "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -23,7 +24,7 @@ def test_plan_builder_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "built=" in r.stdout and "pmx fuzz:" in r.stdout and "ERROR" not in r.stderr
+    assert "built=" in r.stdout and "pmx fuzz:" in r.stdout and "vmd fuzz:" in r.stdout and "ERROR" not in r.stderr
 
 
 def test_oracle_restatement_under_asan_ubsan(tmp_path):
