@@ -300,7 +300,39 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     out["config1_600_frames"] = c1
     for b in (d_pal, d_w, d_a):
         b.free()
-    dm1.close()
+
+    # The drop-in call as the viewer would make it: host palette + rates in, 32-byte vertices out to host
+    # memory (PCIe inclusive, synchronous) -- pageable numpy buffers vs page-locked ones.
+    try:
+        import ctypes as C
+        from simple_mmd_renderer_amd.engine import PinnedArray
+        pal1, rt1 = pals1[7].copy(), rates1[7].copy()
+        out_pg = np.empty((m1.nv, 8), np.float32)
+        f32p = C.POINTER(C.c_float)
+
+        def frame(pal, rt, out):
+            api.check(api.lib().mmdx_deform_vertex32(dm1.h, rt.ctypes.data_as(f32p), pal.ctypes.data_as(f32p),
+                                                     C.c_float(0.1), out.ctypes.data))
+        import time as _t
+        def wall(fn, n=200):
+            for _ in range(10):
+                fn()
+            t0 = _t.perf_counter()
+            for _ in range(n):
+                fn()
+            return (_t.perf_counter() - t0) / n * 1e3
+        pg = wall(lambda: frame(pal1, rt1, out_pg))
+        p_pal, p_rt, p_out = PinnedArray(pal1.shape, np.float32), PinnedArray(rt1.shape, np.float32), PinnedArray((m1.nv, 8), np.float32)
+        p_pal.array[:] = pal1; p_rt.array[:] = rt1
+        pn = wall(lambda: frame(p_pal.array, p_rt.array, p_out.array))
+        assert np.array_equal(p_out.array.view(np.uint32), out_pg.view(np.uint32))
+        out["config1_frame_host_io"] = {"vertices": m1.nv, "pageable_ms": pg, "pinned_ms": pn,
+                                        "pinned_vertices_per_s": m1.nv / (pn * 1e-3),
+                                        "note": "mmdx_deform_vertex32, host in / host out, PCIe + sync included"}
+        for x in (p_pal, p_rt, p_out):
+            x.free()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["config1_frame_host_io"] = {"error": repr(e)}
 
     # PMX loader (the first "next" row): the config-1 model written as a PMX 2.0 file, parsed by this
     # repo's loader (C++, csrc/pmx.cpp) and by the reference's FileReader + PmxReader -- host CPU both.
@@ -327,6 +359,8 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
         out["pmx_loader_config1_file"] = c
     except Exception as e:                                   # pragma: no cover - reporting only
         out["pmx_loader_config1_file"] = {"error": repr(e)}
+
+    dm1.close()
 
     # config 5: 262 144 verts, 512 bones, 1024 morphs x 4096 entries, fp16 positions
     m5 = synth.make_config("config5_256k")

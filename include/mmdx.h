@@ -204,6 +204,10 @@ MMDX_API mmdx_status mmdx_profile_collect(mmdx_model_t model, uint32_t *n_calls,
  * the HIP runtime themselves. */
 MMDX_API mmdx_status mmdx_device_malloc(void **ptr, size_t bytes);
 MMDX_API mmdx_status mmdx_device_free(void *ptr);
+/* Page-locked host memory: palettes / rates / vertex buffers handed to mmdx_deform*() from here move
+ * over PCIe by DMA without the runtime's staging copy (the single-model drop-in path). */
+MMDX_API mmdx_status mmdx_host_malloc(void **ptr, size_t bytes);
+MMDX_API mmdx_status mmdx_host_free(void *ptr);
 MMDX_API mmdx_status mmdx_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);
 MMDX_API mmdx_status mmdx_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
 MMDX_API mmdx_status mmdx_device_memset(void *dst_device, int value, size_t bytes);

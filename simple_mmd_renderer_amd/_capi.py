@@ -83,6 +83,8 @@ SIGNATURES = {
     "mmdx_profile_collect": (C.c_int32, [C.c_void_p, _u32p, _f32p, _f32p]),
     "mmdx_device_malloc": (C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
     "mmdx_device_free": (C.c_int32, [C.c_void_p]),
+    "mmdx_host_malloc": (C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "mmdx_host_free": (C.c_int32, [C.c_void_p]),
     "mmdx_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mmdx_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mmdx_device_memset": (C.c_int32, [C.c_void_p, C.c_int, C.c_size_t]),

@@ -388,6 +388,10 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         dp.morphed = static_cast<float *>(m->morphed.ptr);
         if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
             HIP_TRY(launch_morph_apply(p.f16, dp, &f, st));      // flatten fused in: one launch
+        } else if (morph == kMorphFused1) {
+            dp.fused_rates = rates_dev;                           // flatten inside the deform kernel
+            dp.slot_top = f.slot_top; dp.chain_off = f.chain_off; dp.chain_rate = f.chain_rate;
+            dp.nm = p.nm;
         } else {
             HIP_TRY(launch_flatten(f, st));
             if (morph == kMorphShared) HIP_TRY(launch_morph_apply(p.f16, dp, nullptr, st));
@@ -604,6 +608,18 @@ mmdx_status mmdx_device_malloc(void **ptr, size_t bytes) {
     if (!ptr) return fail(MMDX_ERR_INVALID_ARGUMENT, "ptr is NULL");
     HIP_TRY(hipSetDevice(g_device));
     HIP_TRY(hipMalloc(ptr, bytes ? bytes : 16));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_host_malloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(MMDX_ERR_INVALID_ARGUMENT, "ptr is NULL");
+    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_host_free(void *ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return MMDX_OK;
 }
 

@@ -230,6 +230,20 @@ __device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint
     }
 }
 
+// Group-morph recursion of one slot (UpdateMorphTransform, poser_impl.inl:328-339): rate[top] times the
+// nested groups' sub-rates, with the `< 1e-7` skip after every factor; a skipped slot weighs 0.
+__device__ __forceinline__ float slot_weight(const float *rates, const uint32_t *slot_top,
+                                             const uint32_t *chain_off, const float *chain_rate,
+                                             uint32_t s) {
+    float r = rates[slot_top[s]];
+    bool skip = r < kMorphEps;
+    for (uint32_t c = chain_off[s]; !skip && c < chain_off[s + 1]; ++c) {
+        r = chain_rate[c] * r;
+        skip = r < kMorphEps;
+    }
+    return skip ? 0.f : r;
+}
+
 // ---- the deformation kernel ----------------------------------------------------------------------
 // THREADS = 512: one sorted slot per lane, 8 waves per workgroup; THREADS = 256: two slots per lane.
 template <int THREADS, int LAYOUT, int MORPH, bool F16>
@@ -290,7 +304,13 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     // 2. morph slot weights of the group -> LDS
     if constexpr (MORPH == kMorphFused1) {
         float *wl = reinterpret_cast<float *>(smem + p.w_off);
-        for (uint32_t s = tid; s <= p.ns; s += THREADS) wl[s] = p.wslot[size_t(inst0) * (p.ns + 1) + s];
+        if (p.fused_rates) {   // single-instance call: flatten in here, no separate launch
+            const float *rates = p.fused_rates + size_t(inst0) * p.nm;
+            for (uint32_t s = tid; s <= p.ns; s += THREADS)
+                wl[s] = s < p.ns ? slot_weight(rates, p.slot_top, p.chain_off, p.chain_rate, s) : 0.f;
+        } else {
+            for (uint32_t s = tid; s <= p.ns; s += THREADS) wl[s] = p.wslot[size_t(inst0) * (p.ns + 1) + s];
+        }
     } else if constexpr (MORPH == kMorphFused4) {
         float4 *wl4 = reinterpret_cast<float4 *>(smem + p.w_off);
         const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t(inst0 / 4) * (p.ns + 1);
@@ -552,18 +572,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
 // ---- shared morph pass: morphed[gs] = base[gs] + sum(offset*rate), once per call ------------------
 // FUSED_FLATTEN: every workgroup first evaluates the group-morph chains of all slots into LDS
 // (UpdateMorphTransform's recursion; NS is a few hundred), saving the separate flatten launch.
-__device__ __forceinline__ float slot_weight(const float *rates, const uint32_t *slot_top,
-                                             const uint32_t *chain_off, const float *chain_rate,
-                                             uint32_t s) {
-    float r = rates[slot_top[s]];
-    bool skip = r < kMorphEps;
-    for (uint32_t c = chain_off[s]; !skip && c < chain_off[s + 1]; ++c) {
-        r = chain_rate[c] * r;
-        skip = r < kMorphEps;
-    }
-    return skip ? 0.f : r;
-}
-
 template <bool F16, bool FUSED_FLATTEN>
 __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParams p,
                                                                const FlattenParams f) {

@@ -41,6 +41,12 @@ struct DeformParams {
                                  // kMorphFused4: float4 [ceil(NI/4)][NS+1] (instance quads)
                                  // morph_apply : f32 [NS+1]
     float *morphed;              // f32 [NV][3] sorted order (kMorphShared)
+    // kMorphFused1 with fused_rates != nullptr: slot weights are evaluated inside the kernel from the
+    // raw morph rates [NI][NM] (saves the flatten launch of a single-model frame)
+    const float *fused_rates;
+    const uint32_t *slot_top, *chain_off;
+    const float *chain_rate;
+    uint32_t nm;
     void *out_a;
     void *out_b;
     uint32_t nv, nb, ns, ni;

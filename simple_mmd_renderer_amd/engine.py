@@ -91,6 +91,25 @@ class DeviceBuffer:
             pass
 
 
+class PinnedArray:
+    """A numpy view of page-locked host memory (mmdx_host_malloc): frame buffers that cross PCIe by DMA."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        api.check(api.lib().mmdx_host_malloc(C.byref(p), nbytes))
+        self.ptr = p.value
+        buf = (C.c_char * max(nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def free(self) -> None:
+        if self.ptr:
+            self.array = None
+            api.lib().mmdx_host_free(self.ptr)
+            self.ptr = None
+
+
 class DeformModel:
     """mmdx_model_t: the model compiled to the kernels' HBM layout, resident on one GPU."""
 
