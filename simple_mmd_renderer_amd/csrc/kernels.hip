@@ -219,14 +219,26 @@ __device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint
             body(v2f{r.x, r.y}, r.z, __float_as_uint(r.w));
         }
     };
-    for (uint32_t j = 0; j < len; j += 4) {
-        const uint32_t last = len - 1;
-        const Raw r0 = ent[size_t(j) * 64], r1 = ent[size_t(min(j + 1, last)) * 64],
-                  r2 = ent[size_t(min(j + 2, last)) * 64], r3 = ent[size_t(min(j + 3, last)) * 64];
-        apply(r0);
-        if (j + 1 < len) apply(r1);
-        if (j + 2 < len) apply(r2);
-        if (j + 3 < len) apply(r3);
+    // software-pipelined: the next B entries are in flight while the current B are consumed (the
+    // gather is a chain of L2 round trips; with ~3 resident waves per SIMD nothing else hides them)
+    constexpr uint32_t B = F16 ? 8 : 4;     // 8-byte entries: twice as many per register budget
+    if (len == 0) return;
+    const uint32_t last = len - 1;
+    Raw cur[B], nxt[B];
+#pragma unroll
+    for (uint32_t i = 0; i < B; ++i) cur[i] = ent[size_t(min(i, last)) * 64];
+    for (uint32_t j = 0; j < len; j += B) {
+#pragma unroll
+        for (uint32_t i = 0; i < B; ++i) nxt[i] = cur[i];
+        if (j + B < len) {
+#pragma unroll
+            for (uint32_t i = 0; i < B; ++i) nxt[i] = ent[size_t(min(j + B + i, last)) * 64];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < B; ++i)
+            if (i == 0 || j + i < len) apply(cur[i]);
+#pragma unroll
+        for (uint32_t i = 0; i < B; ++i) cur[i] = nxt[i];
     }
 }
 
