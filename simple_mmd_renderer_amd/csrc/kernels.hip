@@ -221,7 +221,7 @@ __device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint
     };
     // software-pipelined: the next B entries are in flight while the current B are consumed (the
     // gather is a chain of L2 round trips; with ~3 resident waves per SIMD nothing else hides them)
-    constexpr uint32_t B = F16 ? 8 : 4;     // 8-byte entries: twice as many per register budget
+    constexpr uint32_t B = 4;   // deeper (8) costs the fused kernels a wave per SIMD and loses: measured
     if (len == 0) return;
     const uint32_t last = len - 1;
     Raw cur[B], nxt[B];
