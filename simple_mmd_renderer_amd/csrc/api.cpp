@@ -418,7 +418,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         const uint32_t target = uint32_t(env_int("MMDX_LDS_TARGET", 42 * 1024));
         uint32_t so, wo;
         const size_t fixed = deform_lds_bytes(layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);
-        const size_t per = size_t(p.max_tile_bones) * 48 + (morph == kMorphFused4 ? (size_t(p.ns) + 1) * 4 : 0);
+        const size_t per = size_t(p.max_tile_bones) * 48;
         uint32_t g = target > fixed ? uint32_t((target - fixed) / per) : 0u;
         g = std::min(g, 32u);
         if (g >= 8) g &= ~3u;   // measured: 16 beats 17 (even split of 1024 instances, aligned strides)

@@ -323,12 +323,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         } else {
             for (uint32_t s = tid; s <= p.ns; s += THREADS) wl[s] = p.wslot[size_t(inst0) * (p.ns + 1) + s];
         }
-    } else if constexpr (MORPH == kMorphFused4) {
-        float4 *wl4 = reinterpret_cast<float4 *>(smem + p.w_off);
-        const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t(inst0 / 4) * (p.ns + 1);
-        const uint32_t n = ((gcount + 3) / 4) * (p.ns + 1);
-        for (uint32_t i = tid; i < n; i += THREADS) wl4[i] = src[i];
-    }
+    }   // kMorphFused4 stages the weights of one instance quad at a time, inside the quad loop
 
     // 3. static per-vertex data -> registers (sorted slot s = tid + k*THREADS)
     Slot sl[VPT];
@@ -523,11 +518,19 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         }
         run_instance(0, cxy, cz);
     } else {
-        const float4 *wl4 = reinterpret_cast<const float4 *>(smem + p.w_off);
+        // Slot weights of ONE instance quad live in LDS at a time ((NS+1) x float4): the group can then
+        // be large (static data, palettes and the prologue amortise over more instances) without the
+        // weights eating the LDS.
+        float4 *wq = reinterpret_cast<float4 *>(smem + p.w_off);
         for (uint32_t g0 = 0; g0 < gcount; g0 += 4) {
             v2f dxy[VPT][4];
             float dz[VPT][4];
-            const float4 *wq = wl4 + size_t(g0 / 4) * (p.ns + 1);
+            if (g0) __syncthreads();                       // everyone is done with the previous quad's weights
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t((inst0 + g0) / 4) * (p.ns + 1);
+                for (uint32_t i = tid; i <= p.ns; i += THREADS) wq[i] = src[i];
+            }
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
 #pragma unroll
@@ -732,7 +735,7 @@ size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile
     off += 2 * size_t(stage_bytes(layout));
     *w_off = uint32_t(off);
     if (morph == kMorphFused1) off += (size_t(ns + 1) * 4 + 15) / 16 * 16;
-    else if (morph == kMorphFused4) off += size_t((group + 3) / 4) * (ns + 1) * 16;
+    else if (morph == kMorphFused4) off += size_t(ns + 1) * 16;   // one instance quad at a time
     return off;
 }
 
