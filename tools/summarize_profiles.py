@@ -1,0 +1,38 @@
+"""Condenses what tools/profile_round.sh collected (gpurun_out/<tag>/) into the small summaries
+committed under profiles/<round>/:  python tools/summarize_profiles.py gpurun_out/r01b profiles/r01
+  config3_kernel_stats.csv        rocprofv3 --kernel-trace --stats (verbatim)
+  config3_pmc_hbm_traffic.csv     per-kernel mean/min/max of FETCH_SIZE and WRITE_SIZE (KB as reported,
+                                  separate passes); bench.py reads this file for roofline.traffic
+  config3_bench.json              the plain bench line of the same box
+  config3_bench_under_rocprof.json the line printed while tracing (HIP-event time to compare with the trace)
+"""
+import collections
+import csv
+import os
+import shutil
+import sys
+
+
+def main(src, dst):
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(dst, "config3_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "config3_bench.json"))
+    shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "config3_bench_under_rocprof.json"))
+    rows = []
+    for counter, path in (("FETCH_SIZE", "pmc_fetch/fetch_counter_collection.csv"),
+                          ("WRITE_SIZE", "pmc_write/write_counter_collection.csv")):
+        per = collections.OrderedDict()
+        with open(os.path.join(src, path), newline="") as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] == counter:
+                    per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in per.items():
+            rows.append((counter, k, len(v), sum(v) / len(v), min(v), max(v)))
+    with open(os.path.join(dst, "config3_pmc_hbm_traffic.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["counter", "kernel", "dispatches", "mean_KB", "min_KB", "max_KB"])
+        w.writerows(rows)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
