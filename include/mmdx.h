@@ -274,7 +274,7 @@ MMDX_API mmdx_status mmdx_pmx_get_name(mmdx_pmx_t pmx, int32_t kind, uint32_t in
  * MotionPlayer's name mapping (L/motion/poser_impl.inl:522-537) and Motion::GetMorphPose
  * (L/motion/motion_impl.inl:382-424): the rates a crowd needs -- [instances][morphs], every instance at
  * its own frame -- are produced in HBM, ready for mmdx_deform_batched(MMDX_WEIGHTS_ON_DEVICE).  Bone
- * keyframes are parsed and exposed raw for the host's bone solve. */
+ * keyframes are exposed raw (for a host bone solve) and evaluated on the device further below. */
 typedef struct mmdx_vmd_s *mmdx_vmd_t;
 typedef struct mmdx_morph_motion_s *mmdx_morph_motion_t;
 
@@ -321,6 +321,72 @@ MMDX_API mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t motion, mmdx_mod
                                             uint32_t n_instances, const uint32_t *frames,
                                             uint32_t flags, float *out_weights);
 MMDX_API void mmdx_morph_motion_destroy(mmdx_morph_motion_t motion);
+
+
+/* ---- Bone tracks -> local bone poses on the device; skeleton -> bone palette ---------------------- */
+/* The per-frame input side of the palette.  mmdx_bone_motion_eval replaces
+ * Motion::GetBonePose (L/motion/motion_impl.inl:255-319: clamp to the first / last key, exact key hit,
+ * else per-channel presampled-Bezier blend of the translation and NLerp of the rotation,
+ * L/util/math_impl.inl:1260-1282, :1372-1428) together with VmdReader's control-point set-up
+ * (L/reader/vmd_reader_impl.inl:31-60) and MotionPlayer's name mapping + SeekFrame
+ * (L/motion/poser_impl.inl:522-548), for every (instance, bone) at once.  mmdx_skeleton_solve replaces
+ * Poser::UpdateBoneTransform + UpdateBoneSkinningMatrix (L/motion/poser_impl.inl:142-166, :320-326) in
+ * the reference's evaluation order (pre-physics bones, then post-physics bones, each sorted by transform
+ * level then index, L/motion/poser_impl.inl:107-109, :500-510) and writes the float[16] palettes
+ * mmdx_deform_batched(MMDX_PALETTE_ON_DEVICE) consumes.  Both are bit-exact against libmmd. */
+typedef struct mmdx_bone_motion_s *mmdx_bone_motion_t;
+typedef struct mmdx_skeleton_s *mmdx_skeleton_t;
+
+enum { MMDX_POSES_ON_DEVICE = 1u << 1 };      /* with MMDX_OUT_ON_DEVICE for mmdx_skeleton_solve      */
+enum { MMDX_POSE_FLOATS = 8 };                /* one local pose: translation xyz, 0, quaternion xyzw  */
+
+/* Associate the motion's bone tracks with a model's bones by name (UTF-8); bones without a track keep
+ * the rest pose (zero translation, identity rotation), as after Poser::ResetPosing. */
+MMDX_API mmdx_status mmdx_vmd_bind_bones(mmdx_vmd_t vmd, uint32_t n_bones,
+                                         const char *const *bone_names_utf8,
+                                         mmdx_bone_motion_t *out_motion);
+MMDX_API mmdx_status mmdx_bone_motion_get_info(mmdx_bone_motion_t motion, uint32_t *n_bones,
+                                               uint32_t *n_mapped, uint32_t *n_keys,
+                                               uint32_t *n_curves);
+/* out_poses[i][b][MMDX_POSE_FLOATS] = local pose of model bone b at frames[i].  Stream and device as
+ * for mmdx_morph_motion_eval.  flags: MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE. */
+MMDX_API mmdx_status mmdx_bone_motion_eval(mmdx_bone_motion_t motion, mmdx_model_t model,
+                                           uint32_t n_instances, const uint32_t *frames,
+                                           uint32_t flags, float *out_poses);
+MMDX_API void mmdx_bone_motion_destroy(mmdx_bone_motion_t motion);
+
+enum {                                        /* bits of the PMX bone flag word the skeleton reads    */
+    MMDX_BONE_HAS_IK = 0x0020, MMDX_BONE_APPEND_ROTATE = 0x0100, MMDX_BONE_APPEND_TRANSLATE = 0x0200,
+    MMDX_BONE_POST_PHYSICS = 0x1000
+};
+
+typedef struct mmdx_skeleton_desc {           /* e.g. straight from mmdx_pmx_get_arrays               */
+    uint32_t struct_size;
+    uint32_t n_bones;
+    const float *rest_position;               /* [n_bones][3]                                         */
+    const int32_t *parent;                    /* [n_bones]; outside [0, n_bones) = none               */
+    const int32_t *transform_level;           /* [n_bones] or NULL (all 0); compared as unsigned, like
+                                                 the reference's size_t cast                          */
+    const uint16_t *flags;                    /* [n_bones] PMX bone flag word, or NULL (all 0)        */
+} mmdx_skeleton_desc;
+
+typedef struct mmdx_skeleton_info {
+    uint32_t struct_size;
+    uint32_t n_bones, n_pre_physics, n_post_physics;
+    uint32_t max_chain;                       /* longest parent chain evaluated per bone              */
+    uint32_t reserved0;
+} mmdx_skeleton_info;
+
+/* MMDX_ERR_UNSUPPORTED for skeletons with IK or append (inherit) bones: those need the reference's
+ * serial solve (CCD-IK through double-precision libm) and stay on the host this round. */
+MMDX_API mmdx_status mmdx_skeleton_create(const mmdx_skeleton_desc *desc, mmdx_skeleton_t *out_skeleton);
+MMDX_API mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t skeleton, mmdx_skeleton_info *info);
+/* out_palettes[i][b][16] from poses[i][b][MMDX_POSE_FLOATS].  flags: MMDX_POSES_ON_DEVICE |
+ * MMDX_OUT_ON_DEVICE.  Runs on `model`'s stream when given, so the deform call that follows sees it. */
+MMDX_API mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t skeleton, mmdx_model_t model,
+                                         uint32_t n_instances, const float *poses, uint32_t flags,
+                                         float *out_palettes);
+MMDX_API void mmdx_skeleton_destroy(mmdx_skeleton_t skeleton);
 
 #ifdef __cplusplus
 }

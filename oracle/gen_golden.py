@@ -322,6 +322,41 @@ def main():
                         model_morph_names=np.array(model_names))
     print(f"{'vmd_small.vmd':28s} {len(vdata) / 1024:7.1f} KB + expectations")
 
+    # Rig fixture: bone tracks with Bezier curves -> libmmd's local poses (Motion::GetBonePose) and the
+    # palettes its bone solve makes of them (Poser::PrePhysicsPosing + PostPhysicsPosing) on a small
+    # IK-free skeleton with forward parents, transform levels and post-physics bones.
+    rig_names = ["センター", "上半身", "首", "頭", "左肩", "左腕", "左ひじ", "左手首", "右肩", "右腕", "右ひじ",
+                 "右手首", "下半身", "左足", "左ひざ", "左足首", "右足", "右ひざ", "右足首", "BoneEN"]
+    model_bones = rig_names[:7] + ["動かない"] + rig_names[7:] + ["tail1", "tail2", "tail3"]   # 24 bones, 4 untracked
+    bkeys = synth.make_bone_keys(rig_names, seed=91, keys_per=6, span=200)
+    bkeys.append((rig_names[3], bkeys[20][1], (0.5, 0.25, -1.0), (0.0, 0.0, 0.0, 1.0), None))   # duplicate (name, frame)
+    np.random.RandomState(92).shuffle(bkeys)
+    rdata = vmdmod.write_vmd(bkeys, [("あ", 0, 0.5)])
+    rpath = os.path.join(OUT, "rig_small.vmd")
+    open(rpath, "wb").write(rdata)
+    rmot = ReferenceMotion(rpath)
+    at = np.r_[np.arange(0, 210, 3), [1, 2, 199, 200, 5000]].astype(np.uint32)
+    nbm = len(model_bones)
+    poses = np.zeros((at.size, nbm, 8), np.float32)
+    poses[:, :, 7] = 1.0                                   # untracked bones: ResetPosing's identity
+    for j, n in enumerate(model_bones):
+        for i, f_ in enumerate(at):
+            try:
+                pz = rmot.bone_pose(n.encode("shift_jis"), int(f_))
+            except UnicodeEncodeError:
+                pz = None
+            if pz is not None:
+                poses[i, j] = pz
+    rmot.close()
+    rest, parent, level, flags = synth.make_skeleton(nbm, seed=93, forward_parents=3, post_physics=0.2, levels=3)
+    rsk = Reference.skeleton(rest, parent, level, flags)
+    pals = np.stack([rsk.solve(poses[i]) for i in range(at.size)])
+    rsk.close()
+    np.savez_compressed(os.path.join(OUT, "rig_small_expect.npz"), frames=at, model_bone_names=np.array(model_bones),
+                        expect_poses=poses, rest=rest, parent=parent, level=level, flags=flags,
+                        expect_palettes=pals)
+    print(f"{'rig_small.vmd':28s} {len(rdata) / 1024:7.1f} KB + expectations")
+
     # G13 config-1 plumbing: 20 000 verts / 150 bones / 30 morphs / 600 frames, checksums only.
     cfg = synth.CONFIGS["config1_20k"]
     m = synth.make_config("config1_20k")

@@ -212,6 +212,181 @@ void mmdx_oracle_morph_tracks(uint32_t nm, const uint32_t *key_off, const uint32
     }
 }
 
+/* ---- VMD bone track evaluation (Motion::GetBonePose, L/motion/motion_impl.inl:255-319) ---------- */
+/* Interpolation curve of one channel: control bytes c[0],c[4],c[8],c[12] of a 16-byte block scaled by
+ * 1.0f/127.0f (L/reader/vmd_reader_impl.inl:31-60), stored times 3 by Bezier::SetC, presampled at 32
+ * points unless linear (L/util/math_impl.inl:1393-1428).  `abs` in the bisection is the float overload:
+ * see the include-order note in oracle/ref_harness.cpp. */
+typedef struct { int linear; float pre[32]; } curve_t;
+
+static float curve_poly(float lm, float a, float b) {
+    const float rm = 1.0f - lm;
+    return lm * (rm * (rm * a + lm * b) + lm * lm);
+}
+
+static void curve_setup(const int8_t *c, curve_t *cv) {
+    const float r = 1.0f / 127.0f;
+    const float c0x = (c[0] * r) * 3.0f, c0y = (c[4] * r) * 3.0f;
+    const float c1x = (c[8] * r) * 3.0f, c1y = (c[12] * r) * 3.0f;
+    cv->linear = (c0x == c0y) && (c1x == c1y);
+    if (cv->linear) return;
+    for (size_t i = 0; i < 32; ++i) {
+        const float x = i / 31.0f;
+        float l = 0.0f, rr = 1.0f, lm = 0.0f;
+        for (size_t it = 0; it < 32; ++it) {
+            lm = (l + rr) * 0.5f;
+            const float m = curve_poly(lm, c0x, c1x);
+            const float d = m - x;
+            if ((d < 0.0f ? -d : d) < 1e-7f) break;
+            if (m > x) rr = lm; else l = lm;
+        }
+        cv->pre[i] = curve_poly(lm, c0y, c1y);
+    }
+}
+
+static float curve_eval(const curve_t *cv, float x) {
+    if (cv->linear) return x;
+    x *= 31;
+    const size_t ix = (size_t)x;
+    const float r = x - ix;
+    if (ix < 31) return (1.0f - r) * cv->pre[ix] + r * cv->pre[ix + 1];
+    return cv->pre[31];
+}
+
+extern double sqrt(double);
+
+/* One bone track: frames[n] ascending, tr[n][3], rot[n][4], interp[n][64]; out = t.xyz, 0, q.xyzw.
+ * n == 0: the pose ResetPosing leaves (zero translation, identity rotation). */
+void mmdx_oracle_bone_pose(uint32_t n, const uint32_t *frames, const float *tr, const float *rot,
+                           const int8_t *interp, uint32_t frame, float *out) {
+    float t[3] = {0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    if (n) {
+        uint32_t k = n;                                   /* key to copy verbatim, or n = interpolate */
+        if (frames[0] >= frame) k = 0;
+        else if (frames[n - 1] <= frame) k = n - 1;
+        uint32_t r = 0;
+        if (k == n) {
+            while (frames[r] <= frame) ++r;               /* upper_bound */
+            if (frames[r - 1] == frame) k = r - 1;
+        }
+        if (k < n) {
+            memcpy(t, tr + 3 * (size_t)k, 12);
+            memcpy(q, rot + 4 * (size_t)k, 16);
+        } else {
+            const uint32_t l = r - 1;
+            const float bary = (float)(frame - frames[l]) / (float)(frames[r] - frames[l]);
+            const float *lt = tr + 3 * (size_t)l, *rt = tr + 3 * (size_t)r;
+            const float *lq = rot + 4 * (size_t)l, *rq = rot + 4 * (size_t)r;
+            curve_t cv;
+            float lambda;
+            for (int c = 0; c < 3; ++c) {
+                curve_setup(interp + 64 * (size_t)l + 16 * c, &cv);
+                lambda = curve_eval(&cv, bary);
+                t[c] = lt[c] * (1 - lambda) + rt[c] * lambda;
+            }
+            curve_setup(interp + 64 * (size_t)l + 48, &cv);
+            lambda = curve_eval(&cv, bary);
+            /* NLerp, L/util/math_impl.inl:1260-1282 */
+            if (lambda < (float)MMDX_EPS_D) {
+                memcpy(q, lq, 16);
+            } else if (lambda > (1.0f - (float)MMDX_EPS_D)) {
+                memcpy(q, rq, 16);
+            } else {
+                const float dot = lq[0] * rq[0] + lq[1] * rq[1] + lq[2] * rq[2] + lq[3] * rq[3];
+                const float a = 1.0f - lambda;
+                float v[4];
+                for (int c = 0; c < 4; ++c) {
+                    const float x = a * lq[c], y = lambda * rq[c];
+                    v[c] = dot < 0.0f ? x - y : x + y;
+                }
+                const float norm = (float)sqrt((double)(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+                const float inv = 1.0f / norm;
+                for (int c = 0; c < 4; ++c) q[c] = v[c] * inv;
+            }
+        }
+    }
+    out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; out[3] = 0.0f;
+    memcpy(out + 4, q, 16);
+}
+
+/* ---- bone solve without IK / append (Poser::UpdateBoneTransform, L/motion/poser_impl.inl:142-166;
+ * UpdateBoneSkinningMatrix :320-326; order :99-109, :500-510; reset :366-377) --------------------- */
+static void mat_mul(const float *a, const float *b, float *r) {    /* L/util/math_impl.inl:984-1003 */
+    float t[16];
+    for (int y = 0; y < 4; ++y)
+        for (int x = 0; x < 4; ++x)
+            t[4 * y + x] = a[4 * y] * b[x] + a[4 * y + 1] * b[4 + x] + a[4 * y + 2] * b[8 + x] + a[4 * y + 3] * b[12 + x];
+    memcpy(r, t, 64);
+}
+
+static void mat_identity(float *m) {
+    memset(m, 0, 64);
+    m[0] = m[5] = m[10] = m[15] = 1.0f;
+}
+
+/* rest[NB][3], parent[NB] (outside [0,NB) = none), level[NB] or NULL, flags[NB] or NULL (only the
+ * post-physics bit 0x1000 matters here), poses[NB][8]; out[NB][16].  `scratch` = NB*16 floats + NB
+ * uint32 (local matrices, order).  Returns -1 if a bone has IK or append flags. */
+int mmdx_oracle_bone_solve(uint32_t nb, const float *rest, const int64_t *parent, const int32_t *level,
+                           const uint16_t *flags, const float *poses, float *out, void *scratch) {
+    float *local = (float *)scratch;
+    uint32_t *order = (uint32_t *)(local + 16 * (size_t)nb);
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < nb; ++b)
+        if (flags && (flags[b] & (0x0020 | 0x0100 | 0x0200))) return -1;
+    for (int pass = 0; pass < 2; ++pass) {                /* pre-physics list, then post-physics list */
+        const uint32_t first = n;
+        for (uint32_t b = 0; b < nb; ++b)
+            if ((int)((flags ? flags[b] : 0) >> 12 & 1) == pass) order[n++] = b;
+        for (uint32_t i = first + 1; i < n; ++i) {        /* insertion sort by (size_t level, index) */
+            const uint32_t b = order[i];
+            const uint64_t lb = (uint64_t)(int64_t)(level ? level[b] : 0);
+            uint32_t j = i;
+            while (j > first) {
+                const uint32_t c = order[j - 1];
+                const uint64_t lc = (uint64_t)(int64_t)(level ? level[c] : 0);
+                if (lc < lb || (lc == lb && c < b)) break;
+                order[j] = c;
+                --j;
+            }
+            order[j] = b;
+        }
+    }
+    for (uint32_t b = 0; b < nb; ++b) mat_identity(local + 16 * (size_t)b);
+    for (uint32_t s = 0; s < nb; ++s) {
+        const uint32_t b = order[s];
+        const float *t = poses + 8 * (size_t)b, *r = poses + 8 * (size_t)b + 4;
+        const int has_parent = parent[b] >= 0 && (uint64_t)parent[b] < nb;
+        /* total_rotation_ = morph_rotation_(identity) * rotation_, L/util/math_impl.inl:510-517 */
+        const float ai = 0.0f, aj = 0.0f, ak = 0.0f, ae = 1.0f;
+        const float qi = (ae * r[0] + ai * r[3] + aj * r[2]) - ak * r[1];
+        const float qj = (ae * r[1] + aj * r[3] + ak * r[0]) - ai * r[2];
+        const float qk = (ae * r[2] + ai * r[1] + ak * r[3]) - aj * r[0];
+        const float qe = ae * r[3] - (ai * r[0] + aj * r[1] + ak * r[2]);
+        float tt[3], off[3];
+        for (int k = 0; k < 3; ++k) {
+            tt[k] = 0.0f + t[k];
+            off[k] = has_parent ? rest[3 * (size_t)b + k] - rest[3 * (size_t)parent[b] + k] : rest[3 * (size_t)b + k];
+        }
+        float *m = local + 16 * (size_t)b;
+        /* Quaternion::ToRotateMatrix, L/util/math_impl.inl:540-563 */
+        const float ii = qi * qi, jj = qj * qj, kk = qk * qk, ij = qi * qj, jk = qj * qk, ki = qi * qk;
+        const float ie = qi * qe, je = qj * qe, ke = qk * qe;
+        m[0] = 1.0f - 2.0f * (jj + kk); m[1] = 2.0f * (ij + ke); m[2] = 2.0f * (ki - je); m[3] = 0.0f;
+        m[4] = 2.0f * (ij - ke); m[5] = 1.0f - 2.0f * (kk + ii); m[6] = 2.0f * (jk + ie); m[7] = 0.0f;
+        m[8] = 2.0f * (ki + je); m[9] = 2.0f * (jk - ie); m[10] = 1.0f - 2.0f * (ii + jj); m[11] = 0.0f;
+        m[12] = tt[0] + off[0]; m[13] = tt[1] + off[1]; m[14] = tt[2] + off[2]; m[15] = 1.0f;
+        if (has_parent) mat_mul(m, local + 16 * (size_t)parent[b], m);
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        float g[16];
+        mat_identity(g);
+        g[12] = -rest[3 * (size_t)b]; g[13] = -rest[3 * (size_t)b + 1]; g[14] = -rest[3 * (size_t)b + 2];
+        mat_mul(g, local + 16 * (size_t)b, out + 16 * (size_t)b);
+    }
+    return 0;
+}
+
 /* ---- cpu_baseline timing helpers (kind "port"; seconds, single thread) ---------------------- */
 static double now_s(void) {
     struct timespec ts;

@@ -110,6 +110,39 @@ class Oracle:
                                           _p(out, C.c_float))
         return out
 
+    def bone_pose(self, frames, tr, rot, interp, frame):
+        """Motion::GetBonePose for ONE track (keys ascending; interp int8 [n,64]) -> f32 [8]."""
+        fr = _c(frames, np.uint32).reshape(-1)
+        n = fr.size
+        tr = _c(tr, np.float32).reshape(n, 3) if n else np.zeros((1, 3), np.float32)
+        rot = _c(rot, np.float32).reshape(n, 4) if n else np.zeros((1, 4), np.float32)
+        ip = _c(interp, np.int8).reshape(n, 64) if n else np.zeros((1, 64), np.int8)
+        if n == 0:
+            fr = np.zeros(1, np.uint32)
+        out = np.zeros(8, np.float32)
+        self.lib.mmdx_oracle_bone_pose(C.c_uint32(n), _p(fr, C.c_uint32), _p(tr, C.c_float), _p(rot, C.c_float),
+                                       _p(ip, C.c_int8), C.c_uint32(int(frame)), _p(out, C.c_float))
+        return out
+
+    def bone_solve(self, rest, parent, poses, level=None, flags=None):
+        """Bone solve without IK / append: poses f32 [NB,8] -> palette f32 [NB,16]."""
+        rest = _c(rest, np.float32).reshape(-1, 3)
+        nb = rest.shape[0]
+        parent = _c(parent, np.int64).reshape(nb)
+        poses = _c(poses, np.float32).reshape(nb, 8)
+        lv = _c(level, np.int32).reshape(nb) if level is not None else None
+        fl = _c(flags, np.uint16).reshape(nb) if flags is not None else None
+        out = np.zeros((nb, 16), np.float32)
+        scratch = np.zeros(nb * 17 + 4, np.float32)
+        self.lib.mmdx_oracle_bone_solve.restype = C.c_int
+        rc = self.lib.mmdx_oracle_bone_solve(
+            C.c_uint32(nb), _p(rest, C.c_float), _p(parent, C.c_int64),
+            _p(lv, C.c_int32) if lv is not None else None, _p(fl, C.c_uint16) if fl is not None else None,
+            _p(poses, C.c_float), _p(out, C.c_float), scratch.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise ValueError("oracle bone solve: IK / append bones are not restated")
+        return out
+
     def time_crowd(self, model, rates, palettes, normalize=True):
         """Seconds for one crowd step (shared morph pass + one skinning pass per palette)."""
         t, ids, w = self.normalize(model) if normalize else (
@@ -154,6 +187,13 @@ class ReferenceMotion:
         the motion has no such track."""
         return float(self.lib.mmdref_motion_morph_weight(self.h, sjis_name, C.c_uint32(frame)))
 
+    def bone_pose(self, sjis_name: bytes, frame: int):
+        """Motion::GetBonePose(name, frame) -> f32 [8] (t.xyz, 0, q.xyzw), or None without such a track."""
+        out = np.zeros(8, np.float32)
+        self.lib.mmdref_motion_bone_pose.restype = C.c_int
+        ok = self.lib.mmdref_motion_bone_pose(self.h, sjis_name, C.c_uint32(frame), _p(out, C.c_float))
+        return out if ok else None
+
     def names_match_model(self, ref_model: "Reference") -> int:
         """How many of the model's morph names libmmd finds in the motion (MotionPlayer's mapping)."""
         return int(self.lib.mmdref_motion_count_registered_morphs(self.h, ref_model.h))
@@ -190,6 +230,40 @@ class Reference:
             _p(k[4], C.c_int64), _p(k[5], C.c_float), _p(k[6], C.c_float), _p(k[7], C.c_float),
             _p(k[8], C.c_int64), _p(k[9], C.c_int32), _p(k[10], C.c_uint32), _p(k[11], C.c_uint32),
             _p(k[12], C.c_float), C.c_int(1 if normalize else 0)))
+
+    @classmethod
+    def skeleton(cls, rest, parent, level=None, flags=None, append_parent=None, append_ratio=None) -> "Reference":
+        """Bones-only libmmd model + Poser, for the bone solve (set_bone_pose / pose / get_palette)."""
+        if not reference_available():
+            raise RuntimeError("oracle/_ref/libmmd_ref.so not built (needs /root/reference)")
+        self = cls.__new__(cls)
+        lib = C.CDLL(REF_SO)
+        lib.mmdref_create_skeleton.restype = C.c_void_p
+        rest = _c(rest, np.float32).reshape(-1, 3)
+        nb = rest.shape[0]
+        keep = [rest, _c(parent, np.int64).reshape(nb),
+                _c(level, np.int32).reshape(nb) if level is not None else None,
+                _c(flags, np.uint16).reshape(nb) if flags is not None else None,
+                _c(append_parent, np.int64).reshape(nb) if append_parent is not None else None,
+                _c(append_ratio, np.float32).reshape(nb) if append_ratio is not None else None]
+        types = [C.c_float, C.c_int64, C.c_int32, C.c_uint16, C.c_int64, C.c_float]
+        h = lib.mmdref_create_skeleton(C.c_uint32(nb), *[_p(a, t) if a is not None else None
+                                                         for a, t in zip(keep, types)])
+        self.lib, self._keep, self.h = lib, keep, C.c_void_p(h)
+
+        class _Dims:
+            pass
+        self.model = _Dims()
+        self.model.nv, self.model.nb, self.model.nm = 0, nb, 0
+        return self
+
+    def solve(self, poses):
+        """ResetPosing-equivalent state + the given local poses [NB,8] -> palette [NB,16]."""
+        poses = _c(poses, np.float32).reshape(self.model.nb, 8)
+        for b in range(self.model.nb):
+            self.set_bone_pose(b, poses[b, 0:3], poses[b, 4:8])
+        self.pose()
+        return self.get_palette()
 
     @classmethod
     def from_pmx(cls, path: str) -> "Reference":

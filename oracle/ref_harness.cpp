@@ -19,6 +19,14 @@
 //                                  here, so the 10 lines of arithmetic are re-expressed below)
 // (L/ = 3rd_party/libmmd/include/mmd/)
 
+// Include order matters for ONE reference function: Bezier::interpolate calls an unqualified `abs`
+// (L/util/math_impl.inl:1417).  The viewer's translation unit sees <math.h>/<stdlib.h> (through sokol
+// and imgui, main.cpp:10-20) before mmd.hxx (main.cpp:22), so ::abs(float) is the overload it binds;
+// with mmd.hxx first g++ binds ::abs(int) and every non-linear curve collapses to a constant.  The
+// oracle follows the application.
+#include <math.h>
+#include <stdlib.h>
+
 #include <mmd/mmd.hxx>
 
 #include <chrono>
@@ -254,6 +262,49 @@ uint32_t mmdref_motion_count_registered_morphs(void *motion, void *ref) {
     for (size_t i = 0; i < r->model.GetMorphNum(); ++i)
         if (m->IsMorphRegistered(r->model.GetMorph(i).GetName())) ++n;
     return n;
+}
+
+// Motion::GetBonePose (motion_impl.inl:255-319) for the track stored under the given Shift-JIS name:
+// out = translation xyz, 0, rotation xyzw.  Returns 0 if no such track.
+int mmdref_motion_bone_pose(void *h, const char *sjis_name, uint32_t frame, float *out) {
+    mmd::Motion *m = static_cast<mmd::Motion *>(h);
+    const std::wstring key = mmd::ShiftJISToUTF16String(std::string(sjis_name));
+    if (!m->IsBoneRegistered(key)) return 0;
+    const mmd::Motion::BonePose pose = m->GetBonePose(key, size_t(frame));
+    for (int k = 0; k < 3; ++k) out[k] = pose.GetTranslation().v[k];
+    out[3] = 0.f;
+    for (int k = 0; k < 4; ++k) out[4 + k] = pose.GetRotation().v[k];
+    return 1;
+}
+
+// A bones-only model (no vertices, no morphs) for the bone solve: Poser ctor ordering
+// (poser_impl.inl:99-109), UpdateBoneTransform / UpdateBoneSkinningMatrix (:142-166, :320-326).
+// flags = PMX bone flag word (0x20 IK, 0x100/0x200 append rotate/translate, 0x1000 post-physics);
+// append_parent / append_ratio may be NULL when no bone appends.
+void *mmdref_create_skeleton(uint32_t nb, const float *bone_pos, const int64_t *bone_parent,
+                             const int32_t *level, const uint16_t *flags,
+                             const int64_t *append_parent, const float *append_ratio) {
+    Ref *r = new Ref;
+    mmd::Model &m = r->model;
+    m.SetExtraUVNumber(0);
+    for (uint32_t b = 0; b < nb; ++b) {
+        mmd::Model::Bone &bone = m.NewBone();
+        const uint16_t f = flags ? flags[b] : 0;
+        bone.SetName(L"b" + std::to_wstring(b));
+        bone.SetPosition(V3(bone_pos + 3 * b));
+        bone.SetParentIndex(bone_parent[b] < 0 ? size_t(-1) : size_t(bone_parent[b]));
+        bone.SetTransformLevel(size_t(level ? level[b] : 0));
+        bone.SetHasIK(false);
+        bone.SetAppendRotate((f & 0x0100) != 0);
+        bone.SetAppendTranslate((f & 0x0200) != 0);
+        if (f & 0x0300) {
+            bone.SetAppendIndex(append_parent[b] < 0 ? size_t(-1) : size_t(append_parent[b]));
+            bone.SetAppendRatio(append_ratio[b]);
+        }
+        bone.SetPostPhysics((f & 0x1000) != 0);
+    }
+    r->poser = new mmd::Poser(r->model);
+    return r;
 }
 
 void mmdref_destroy(void *h) { delete static_cast<Ref *>(h); }

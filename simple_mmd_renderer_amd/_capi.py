@@ -110,6 +110,14 @@ SIGNATURES = {
     "mmdx_morph_motion_get_info": (C.c_int32, [C.c_void_p, _u32p, _u32p, _u32p]),
     "mmdx_morph_motion_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mmdx_morph_motion_destroy": (None, [C.c_void_p]),
+    "mmdx_vmd_bind_bones": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]),
+    "mmdx_bone_motion_get_info": (C.c_int32, [C.c_void_p, _u32p, _u32p, _u32p, _u32p]),
+    "mmdx_bone_motion_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "mmdx_bone_motion_destroy": (None, [C.c_void_p]),
+    "mmdx_skeleton_create": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mmdx_skeleton_get_info": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "mmdx_skeleton_solve": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "mmdx_skeleton_destroy": (None, [C.c_void_p]),
 }
 
 _lib = None

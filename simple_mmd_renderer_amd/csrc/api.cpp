@@ -18,6 +18,7 @@
 #include "error.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
+#include "rig_kernels.hpp"
 
 using namespace mmdx;
 
@@ -158,6 +159,18 @@ void mmdx::morph_motion_release_device(MorphMotionDevice &d) {
     d.frames_in_bytes = d.out_bytes = 0;
     d.device = -1;
 }
+
+mmdx_status mmdx::resolve_stream(mmdx_model_t model, int *device, hipStream_t *stream) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MMDX_ERR_NO_DEVICE, "no HIP device available (motion and rig evaluation run on the GPU)");
+    const bool on_model = model && model->device >= 0;
+    *device = on_model ? model->device : g_device;
+    *stream = on_model ? model->stream : nullptr;
+    HIP_TRY(hipSetDevice(*device));
+    return MMDX_OK;
+}
+mmdx_status mmdx::hip_status(hipError_t e, const char *what) { return hip_fail(e, what); }
 
 extern "C" {
 

@@ -1,0 +1,152 @@
+// rig.cpp -- host-side compilation of bone tracks and of the skeleton (no HIP in this file, so the
+// sanitizer drivers can link it).  The device kernels are in rig_kernels.hip, the C ABI in rig_api.cpp.
+//
+// Reference semantics followed (L/ = 3rd_party/libmmd/include/mmd/):
+//   control points: byte * (1.0f/127.0f), bytes [0],[4],[8],[12] of each 16-byte block
+//                                                      L/reader/vmd_reader_impl.inl:31-60
+//   Bezier<float,32>::SetC stores the points times 3, a curve is linear when x == y for both points;
+//   otherwise 32 samples at i/31 are taken by a 32-step float bisection on the x polynomial
+//                                                      L/util/math_impl.inl:1393-1428
+//   evaluation order of the bone solve: pre-physics bones then post-physics bones, each sorted by
+//   (transform level as size_t, index)                 L/motion/poser_impl.inl:99-109, :500-510
+//   local offset = rest - parent's rest (or rest), global offset = translate(-rest)
+//                                                      L/motion/poser_impl.inl:36-45
+//
+// Platform note on the bisection's `abs(m-x)` (math_impl.inl:1417): the call is unqualified, so which
+// overload it finds depends on the headers seen before <mmd/mmd.hxx>.  The viewer includes sokol and
+// imgui first (main.cpp:10-22; they pull in <math.h>/<stdlib.h>), which makes ::abs(float) visible --
+// the floating-point test below.  A translation unit that includes mmd.hxx first binds ::abs(int) under
+// g++ and every curve degenerates to a constant; oracle/ref_harness.cpp therefore mirrors the viewer's
+// include order.
+#include "rig.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace mmdx {
+
+bool presample_curve(int8_t x0, int8_t y0, int8_t x1, int8_t y1, float out[kCurveSamples]) {
+    const float r = 1.0f / 127.0f;
+    const float c0x = (float(int(x0)) * r) * 3.0f, c0y = (float(int(y0)) * r) * 3.0f;
+    const float c1x = (float(int(x1)) * r) * 3.0f, c1y = (float(int(y1)) * r) * 3.0f;
+    if (c0x == c0y && c1x == c1y) return false;
+    for (uint32_t i = 0; i < kCurveSamples; ++i) {
+        const float x = float(i) / float(kCurveSamples - 1);
+        float lo = 0.0f, hi = 1.0f, m, lm = 0.0f, rm;
+        for (int it = 0; it < 32; ++it) {
+            lm = (lo + hi) * 0.5f;
+            rm = 1.0f - lm;
+            m = lm * (rm * (rm * c0x + lm * c1x) + lm * lm);
+            if (std::fabs(m - x) < 1e-7f) break;
+            if (m > x) hi = lm; else lo = lm;
+        }
+        rm = 1.0f - lm;
+        out[i] = lm * (rm * (rm * c0y + lm * c1y) + lm * lm);
+    }
+    return true;
+}
+
+void build_bone_motion(const std::vector<std::string> &track_names, const std::vector<uint32_t> &track_off,
+                       const mmdx_vmd_bone_key *keys, uint32_t n_bones, const char *const *bone_names,
+                       BoneMotionHost &out) {
+    std::map<std::string, uint32_t> track_of;
+    for (uint32_t t = 0; t < track_names.size(); ++t) track_of.emplace(track_names[t], t);
+    std::map<uint32_t, uint32_t> curve_of;   // packed control bytes -> table id
+    out = BoneMotionHost();
+    out.nb = n_bones;
+    out.key_off.push_back(0);
+    float table[kCurveSamples];
+    for (uint32_t b = 0; b < n_bones; ++b) {
+        auto it = bone_names[b] ? track_of.find(bone_names[b]) : track_of.end();
+        if (it != track_of.end()) {
+            ++out.n_mapped;
+            for (uint32_t k = track_off[it->second]; k < track_off[it->second + 1]; ++k) {
+                const mmdx_vmd_bone_key &key = keys[k];
+                out.key_frame.push_back(key.frame);
+                out.key_tr.insert(out.key_tr.end(), {key.translation[0], key.translation[1], key.translation[2], 0.0f});
+                out.key_rot.insert(out.key_rot.end(), key.rotation, key.rotation + 4);
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int8_t *c = key.interpolation + 16 * ch;
+                    uint32_t packed;
+                    const int8_t pts[4] = {c[0], c[4], c[8], c[12]};
+                    std::memcpy(&packed, pts, 4);
+                    auto cit = curve_of.find(packed);
+                    if (cit == curve_of.end()) {
+                        uint32_t id = kLinearCurve;
+                        if (presample_curve(pts[0], pts[1], pts[2], pts[3], table)) {
+                            id = uint32_t(out.lut.size() / kCurveSamples);
+                            out.lut.insert(out.lut.end(), table, table + kCurveSamples);
+                        }
+                        cit = curve_of.emplace(packed, id).first;
+                    }
+                    out.key_curve.push_back(cit->second);
+                }
+            }
+        }
+        out.key_off.push_back(uint32_t(out.key_frame.size()));
+    }
+}
+
+std::string build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out) {
+    out = SkeletonPlan();
+    const uint32_t nb = d.n_bones;
+    if (nb && (!d.rest_position || !d.parent)) return "rest_position / parent is NULL";
+    out.nb = nb;
+    std::vector<uint32_t> pre, post;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint16_t f = d.flags ? d.flags[b] : 0;
+        if (f & (MMDX_BONE_HAS_IK | MMDX_BONE_APPEND_ROTATE | MMDX_BONE_APPEND_TRANSLATE)) out.serial = true;
+        (f & MMDX_BONE_POST_PHYSICS ? post : pre).push_back(b);
+    }
+    auto level = [&](uint32_t b) { return d.transform_level ? uint32_t(d.transform_level[b]) : 0u; };
+    auto by_level = [&](uint32_t a, uint32_t b) { return level(a) != level(b) ? level(a) < level(b) : a < b; };
+    std::sort(pre.begin(), pre.end(), by_level);
+    std::sort(post.begin(), post.end(), by_level);
+    out.n_pre = uint32_t(pre.size());
+    out.n_post = uint32_t(post.size());
+    out.order = pre;
+    out.order.insert(out.order.end(), post.begin(), post.end());
+    std::vector<uint32_t> seq(nb);
+    for (uint32_t i = 0; i < nb; ++i) seq[out.order[i]] = i;
+
+    auto parent_of = [&](uint32_t b) -> int64_t {
+        const int32_t p = d.parent[b];
+        return (p >= 0 && uint32_t(p) < nb) ? int64_t(p) : -1;
+    };
+    out.local_offset.resize(size_t(nb) * 4, 0.0f);
+    out.neg_rest.resize(size_t(nb) * 4, 0.0f);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const float *pos = d.rest_position + 3 * size_t(b);
+        const int64_t p = parent_of(b);
+        for (int k = 0; k < 3; ++k) {
+            out.local_offset[4 * size_t(b) + k] = p >= 0 ? pos[k] - d.rest_position[3 * size_t(p) + k] : pos[k];
+            out.neg_rest[4 * size_t(b) + k] = -pos[k];
+        }
+    }
+    // Parent chains.  A parent that comes LATER in the evaluation sequence still holds the identity
+    // its local matrix was reset to (PrePhysicsPosing, poser_impl.inl:371): the chain then starts with
+    // kIdentityParent and that product is carried out like any other.
+    out.chain_off.push_back(0);
+    std::vector<uint32_t> rev;
+    for (uint32_t b = 0; b < nb; ++b) {
+        rev.clear();
+        uint32_t c = b;
+        for (;;) {
+            rev.push_back(c);
+            const int64_t p = parent_of(c);
+            if (p < 0) break;
+            if (uint32_t(p) == c) return "bone " + std::to_string(c) + " is its own parent";
+            if (seq[uint32_t(p)] > seq[c]) { rev.push_back(kIdentityParent); break; }
+            c = uint32_t(p);
+        }
+        if (out.chain.size() + rev.size() > (size_t(1) << 26)) return "parent chains too long for the parallel bone solve";
+        out.max_chain = std::max(out.max_chain, uint32_t(rev.size()));
+        out.chain.insert(out.chain.end(), rev.rbegin(), rev.rend());
+        out.chain_off.push_back(uint32_t(out.chain.size()));
+    }
+    return "";
+}
+
+}  // namespace mmdx

@@ -1,0 +1,69 @@
+// rig.hpp -- bone tracks and skeleton: host-side compilation (rig.cpp, no HIP) and the parameter
+// blocks of the device kernels (rig_kernels.hip), driven by the C ABI in rig_api.cpp.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mmdx.h"
+
+namespace mmdx {
+
+constexpr uint32_t kLinearCurve = 0xFFFFFFFFu;
+constexpr uint32_t kCurveSamples = 32;          // Bezier<float, 32>, L/util/math.inl:446
+constexpr uint32_t kIdentityParent = 0xFFFFFFFFu;
+
+// ---- bone tracks bound to a model's bones ------------------------------------------------------
+struct BoneMotionHost {
+    uint32_t nb = 0, n_mapped = 0;
+    std::vector<uint32_t> key_off;              // [nb+1]
+    std::vector<uint32_t> key_frame;            // [K] ascending inside a bone
+    std::vector<float> key_tr;                  // [K][4]  translation xyz, 0
+    std::vector<float> key_rot;                 // [K][4]  quaternion xyzw
+    std::vector<uint32_t> key_curve;            // [K][4]  table id for x, y, z, rotation; kLinearCurve = identity
+    std::vector<float> lut;                     // [n_curves][32] presampled curves
+};
+
+// The reference's presampled interpolation curve for control points (x0,y0,x1,y1) given in 1/127
+// units.  Returns false for a linear curve (no table needed).
+bool presample_curve(int8_t x0, int8_t y0, int8_t x1, int8_t y1, float out[kCurveSamples]);
+
+void build_bone_motion(const std::vector<std::string> &track_names, const std::vector<uint32_t> &track_off,
+                       const mmdx_vmd_bone_key *keys, uint32_t n_bones, const char *const *bone_names,
+                       BoneMotionHost &out);
+
+struct BoneTrackParams {
+    const uint32_t *key_off, *key_frame;
+    const float *key_tr, *key_rot;              // float4 per key
+    const uint32_t *key_curve;                  // uint4 per key
+    const float *lut;
+    const uint32_t *frames;                     // [ni]
+    float *out;                                 // [ni][nb][8]: t.xyz, 0, q.xyzw
+    uint32_t nb, ni;
+};
+
+// ---- skeleton: local poses -> skinning palette --------------------------------------------------
+struct SkeletonPlan {
+    uint32_t nb = 0, n_pre = 0, n_post = 0, max_chain = 0;
+    bool serial = false;                        // IK or append bones present: not a pure parent-chain FK
+    std::vector<uint32_t> order;                // evaluation sequence: pre-physics sorted, then post-physics sorted
+    std::vector<float> local_offset;            // [nb][4] rest position relative to the parent (or absolute)
+    std::vector<float> neg_rest;                // [nb][4] -rest position: translation row of the global offset
+    std::vector<uint32_t> chain_off;            // [nb+1]
+    std::vector<uint32_t> chain;                // per bone: kIdentityParent? then ancestors root-first, the bone last
+};
+
+// Throws nothing; returns an error text ("" = ok).
+std::string build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out);
+
+struct SkeletonParams {
+    const float *poses;                         // [ni][nb][8]
+    float *out;                                 // [ni][nb][16] row-major, row-vector convention
+    const float *local_offset, *neg_rest;       // float4 per bone
+    const uint32_t *chain_off, *chain;
+    uint32_t nb, ni;
+};
+
+}  // namespace mmdx

@@ -1,0 +1,236 @@
+// rig_api.cpp -- C ABI of the bone-track and skeleton entry points (include/mmdx.h) over the HIP runtime.
+// Static tables (keys, curve tables, chains) are uploaded on first use per device; per-call operands may
+// live on the host (copied through handle-owned scratch) or in HBM.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mmdx.h"
+#include "error.hpp"
+#include "rig.hpp"
+#include "rig_kernels.hpp"
+#include "vmd.hpp"
+
+using namespace mmdx;
+
+namespace {
+
+#define HIP_TRY(expr)                                            \
+    do {                                                         \
+        hipError_t e_ = (expr);                                  \
+        if (e_ != hipSuccess) return hip_status(e_, #expr);      \
+    } while (0)
+
+struct Buf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        need = std::max<size_t>(need, 16);
+        if (need <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&ptr, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    template <typename T>
+    hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = ensure(v.size() * sizeof(T));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct mmdx_bone_motion_s {
+    BoneMotionHost host;
+    int device = -1;
+    Buf key_off, key_frame, key_tr, key_rot, key_curve, lut, frames_in, out;
+};
+
+struct mmdx_skeleton_s {
+    SkeletonPlan plan;
+    int device = -1;
+    Buf local_offset, neg_rest, chain_off, chain, poses_in, out;
+};
+
+extern "C" {
+
+mmdx_status mmdx_vmd_bind_bones(mmdx_vmd_t vmd, uint32_t n_bones, const char *const *bone_names,
+                                mmdx_bone_motion_t *out) {
+    if (!vmd || !out || (n_bones && !bone_names)) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    try {
+        std::unique_ptr<mmdx_bone_motion_s> m(new mmdx_bone_motion_s);
+        const VmdBoneTracks t = vmd_bone_tracks(vmd);
+        build_bone_motion(*t.names, *t.off, t.keys, n_bones, bone_names, m->host);
+        *out = m.release();
+    } catch (const std::bad_alloc &) {
+        return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_bone_motion_get_info(mmdx_bone_motion_t m, uint32_t *n_bones, uint32_t *n_mapped,
+                                      uint32_t *n_keys, uint32_t *n_curves) {
+    if (!m) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_bones) *n_bones = m->host.nb;
+    if (n_mapped) *n_mapped = m->host.n_mapped;
+    if (n_keys) *n_keys = uint32_t(m->host.key_frame.size());
+    if (n_curves) *n_curves = uint32_t(m->host.lut.size() / kCurveSamples);
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_bone_motion_eval(mmdx_bone_motion_t m, mmdx_model_t model, uint32_t n_instances,
+                                  const uint32_t *frames, uint32_t flags, float *out_poses) {
+    if (!m || !frames || !out_poses || !n_instances)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
+    int device;
+    hipStream_t st;
+    if (mmdx_status s = resolve_stream(model, &device, &st)) return s;
+    const BoneMotionHost &h = m->host;
+    if (m->device != device) {
+        for (Buf *b : {&m->key_off, &m->key_frame, &m->key_tr, &m->key_rot, &m->key_curve, &m->lut, &m->frames_in,
+                       &m->out})
+            b->release();
+        HIP_TRY(m->key_off.upload(h.key_off));
+        HIP_TRY(m->key_frame.upload(h.key_frame));
+        HIP_TRY(m->key_tr.upload(h.key_tr));
+        HIP_TRY(m->key_rot.upload(h.key_rot));
+        HIP_TRY(m->key_curve.upload(h.key_curve));
+        HIP_TRY(m->lut.upload(h.lut));
+        m->device = device;
+    }
+    BoneTrackParams p;
+    p.key_off = static_cast<const uint32_t *>(m->key_off.ptr);
+    p.key_frame = static_cast<const uint32_t *>(m->key_frame.ptr);
+    p.key_tr = static_cast<const float *>(m->key_tr.ptr);
+    p.key_rot = static_cast<const float *>(m->key_rot.ptr);
+    p.key_curve = static_cast<const uint32_t *>(m->key_curve.ptr);
+    p.lut = static_cast<const float *>(m->lut.ptr);
+    p.nb = h.nb; p.ni = n_instances;
+    if (flags & MMDX_FRAMES_ON_DEVICE) {
+        p.frames = frames;
+    } else {
+        HIP_TRY(m->frames_in.ensure(size_t(n_instances) * 4));
+        HIP_TRY(hipMemcpyAsync(m->frames_in.ptr, frames, size_t(n_instances) * 4, hipMemcpyHostToDevice, st));
+        p.frames = static_cast<const uint32_t *>(m->frames_in.ptr);
+    }
+    const size_t out_bytes = size_t(n_instances) * h.nb * MMDX_POSE_FLOATS * sizeof(float);
+    if (flags & MMDX_OUT_ON_DEVICE) {
+        p.out = out_poses;
+    } else {
+        HIP_TRY(m->out.ensure(out_bytes));
+        p.out = static_cast<float *>(m->out.ptr);
+    }
+    HIP_TRY(launch_bone_track_eval(p, st));
+    if (!(flags & MMDX_OUT_ON_DEVICE)) {
+        if (out_bytes) HIP_TRY(hipMemcpyAsync(out_poses, p.out, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else if (!(flags & MMDX_FRAMES_ON_DEVICE)) {
+        HIP_TRY(hipStreamSynchronize(st));   // borrowed host frames must be consumed before returning
+    }
+    return MMDX_OK;
+}
+
+void mmdx_bone_motion_destroy(mmdx_bone_motion_t m) {
+    if (!m) return;
+    if (m->device >= 0) (void)hipSetDevice(m->device);
+    for (Buf *b : {&m->key_off, &m->key_frame, &m->key_tr, &m->key_rot, &m->key_curve, &m->lut, &m->frames_in,
+                   &m->out})
+        b->release();
+    delete m;
+}
+
+mmdx_status mmdx_skeleton_create(const mmdx_skeleton_desc *desc, mmdx_skeleton_t *out) {
+    if (!desc || !out || desc->struct_size != sizeof(mmdx_skeleton_desc))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or mmdx_skeleton_desc.struct_size mismatch");
+    *out = nullptr;
+    try {
+        std::unique_ptr<mmdx_skeleton_s> s(new mmdx_skeleton_s);
+        const std::string err = build_skeleton(*desc, s->plan);
+        if (!err.empty()) return fail(MMDX_ERR_INVALID_ARGUMENT, "skeleton: " + err);
+        if (s->plan.serial)
+            return fail(MMDX_ERR_UNSUPPORTED,
+                        "skeleton: IK / append bones need the reference's serial solve; not available on the device");
+        *out = s.release();
+    } catch (const std::bad_alloc &) {
+        return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t s, mmdx_skeleton_info *info) {
+    if (!s || !info || info->struct_size != sizeof(mmdx_skeleton_info))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or mmdx_skeleton_info.struct_size mismatch");
+    info->n_bones = s->plan.nb;
+    info->n_pre_physics = s->plan.n_pre;
+    info->n_post_physics = s->plan.n_post;
+    info->max_chain = s->plan.max_chain;
+    info->reserved0 = 0;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances, const float *poses,
+                                uint32_t flags, float *out_palettes) {
+    if (!s || !poses || !out_palettes || !n_instances)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
+    int device;
+    hipStream_t st;
+    if (mmdx_status r = resolve_stream(model, &device, &st)) return r;
+    const SkeletonPlan &pl = s->plan;
+    if (s->device != device) {
+        for (Buf *b : {&s->local_offset, &s->neg_rest, &s->chain_off, &s->chain, &s->poses_in, &s->out}) b->release();
+        HIP_TRY(s->local_offset.upload(pl.local_offset));
+        HIP_TRY(s->neg_rest.upload(pl.neg_rest));
+        HIP_TRY(s->chain_off.upload(pl.chain_off));
+        HIP_TRY(s->chain.upload(pl.chain));
+        s->device = device;
+    }
+    SkeletonParams p;
+    p.local_offset = static_cast<const float *>(s->local_offset.ptr);
+    p.neg_rest = static_cast<const float *>(s->neg_rest.ptr);
+    p.chain_off = static_cast<const uint32_t *>(s->chain_off.ptr);
+    p.chain = static_cast<const uint32_t *>(s->chain.ptr);
+    p.nb = pl.nb; p.ni = n_instances;
+    const size_t in_bytes = size_t(n_instances) * pl.nb * MMDX_POSE_FLOATS * sizeof(float);
+    const size_t out_bytes = size_t(n_instances) * pl.nb * 16 * sizeof(float);
+    if (flags & MMDX_POSES_ON_DEVICE) {
+        p.poses = poses;
+    } else {
+        HIP_TRY(s->poses_in.ensure(in_bytes));
+        if (in_bytes) HIP_TRY(hipMemcpyAsync(s->poses_in.ptr, poses, in_bytes, hipMemcpyHostToDevice, st));
+        p.poses = static_cast<const float *>(s->poses_in.ptr);
+    }
+    if (flags & MMDX_OUT_ON_DEVICE) {
+        p.out = out_palettes;
+    } else {
+        HIP_TRY(s->out.ensure(out_bytes));
+        p.out = static_cast<float *>(s->out.ptr);
+    }
+    HIP_TRY(launch_skeleton_fk(p, st));
+    if (!(flags & MMDX_OUT_ON_DEVICE)) {
+        if (out_bytes) HIP_TRY(hipMemcpyAsync(out_palettes, p.out, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else if (!(flags & MMDX_POSES_ON_DEVICE)) {
+        HIP_TRY(hipStreamSynchronize(st));   // borrowed host poses must be consumed before returning
+    }
+    return MMDX_OK;
+}
+
+void mmdx_skeleton_destroy(mmdx_skeleton_t s) {
+    if (!s) return;
+    if (s->device >= 0) (void)hipSetDevice(s->device);
+    for (Buf *b : {&s->local_offset, &s->neg_rest, &s->chain_off, &s->chain, &s->poses_in, &s->out}) b->release();
+    delete s;
+}
+
+}  // extern "C"

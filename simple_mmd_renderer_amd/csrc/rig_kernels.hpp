@@ -1,0 +1,19 @@
+// rig_kernels.hpp -- launchers of rig_kernels.hip and the stream hand-over from api.cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rig.hpp"
+
+namespace mmdx {
+
+hipError_t launch_bone_track_eval(const BoneTrackParams &p, hipStream_t stream);
+hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream);
+
+// api.cpp: the device and stream a motion / rig call runs on -- the model's own when a (device) model
+// is given, so that the deform call that follows is ordered after it; else the selected device's
+// default stream.  Fails with MMDX_ERR_NO_DEVICE when there is no GPU (no CPU fallback).
+mmdx_status resolve_stream(mmdx_model_t model, int *device, hipStream_t *stream);
+mmdx_status hip_status(hipError_t e, const char *what);
+
+}  // namespace mmdx

@@ -14,8 +14,8 @@
 //   l*(1-t) + r*t with t = float(frame-left)/float(right-left)
 //                                                      Motion::GetMorphPose, L/motion/motion_impl.inl:382-424
 //   (the per-key weight interpolator is a default Bezier, i.e. linear: L/util/math_impl.inl:1350-1354)
-// Bone keyframes (translation, rotation, four Bezier control-point sets) are parsed and exposed raw:
-// they feed the host's bone solve, which stays outside this engine.
+// Bone keyframes (translation, rotation, four Bezier control-point sets) are parsed here, exposed raw,
+// and compiled / evaluated on the device by rig.cpp + rig_kernels.hip (mmdx_vmd_bind_bones).
 //
 // Reference defect worth knowing: on Linux libmmd converts names with iconv_open("UTF-16", "SHIFT-JIS"),
 // whose output starts with a byte-order mark (L/util/dwarf_impl.inl:221-230), so VMD track names never
@@ -89,6 +89,9 @@ const mmdx::MorphMotionHost mmdx::morph_motion_host(const mmdx_morph_motion_s *m
     return {m->nm, m->key_off.data(), m->frames.data(), m->weights.data(), uint32_t(m->frames.size())};
 }
 mmdx::MorphMotionDevice &mmdx::morph_motion_device(mmdx_morph_motion_s *m) { return m->dev; }
+mmdx::VmdBoneTracks mmdx::vmd_bone_tracks(const mmdx_vmd_s *v) {
+    return {&v->bone_names, &v->bone_off, v->bone_keys.data()};
+}
 
 extern "C" {
 

@@ -3,6 +3,8 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <string>
+#include <vector>
 
 #include "../../include/mmdx.h"
 
@@ -26,6 +28,13 @@ struct MorphMotionDevice {        // owned by api.cpp (hipMalloc / hipFree)
 const MorphMotionHost morph_motion_host(const mmdx_morph_motion_s *m);
 MorphMotionDevice &morph_motion_device(mmdx_morph_motion_s *m);
 void morph_motion_release_device(MorphMotionDevice &d);   // api.cpp
+
+struct VmdBoneTracks {            // views into a parsed motion, valid until mmdx_vmd_destroy
+    const std::vector<std::string> *names;    // UTF-8, track order
+    const std::vector<uint32_t> *off;         // [tracks+1] into keys
+    const mmdx_vmd_bone_key *keys;            // sorted by frame inside a track
+};
+VmdBoneTracks vmd_bone_tracks(const mmdx_vmd_s *v);
 
 struct MorphTrackParams {
     const uint32_t *key_off, *key_frames;

@@ -206,3 +206,43 @@ def make_config(name: str) -> FlatModel:
     m = make_model(c["nv"], c["nb"], c["nm"], c["k"], c["seed"])
     m.meta["config"] = name
     return m
+
+
+# ---- synthetic rigs and bone motions ------------------------------
+def make_skeleton(nb: int, seed: int, forward_parents: int = 0, post_physics: float = 0.0, levels: int = 1):
+    """rest f32 [NB,3], parent i32 [NB] (-1 = root), level i32 [NB], flags u16 [NB].
+    Like the model generator: parent(b) uniform in [0,b), bone 0 the root.  `forward_parents` bones get
+    a parent with a LARGER index (legal in PMX; evaluated later unless its level says otherwise),
+    `post_physics` is the fraction of bones flagged 0x1000, `levels` spreads transform levels."""
+    rng = np.random.RandomState(seed)
+    rest = np.stack([rng.uniform(-10, 10, nb), rng.uniform(0, 20, nb), rng.uniform(-1, 1, nb)], 1).astype(np.float32)
+    parent = np.full(nb, -1, np.int32)
+    for b in range(1, nb):
+        parent[b] = rng.randint(0, b)
+    for b in rng.choice(np.arange(1, max(nb - 1, 2)), min(forward_parents, max(nb - 2, 0)), replace=False):
+        parent[b] = rng.randint(b + 1, nb)
+    level = rng.randint(0, levels, nb).astype(np.int32)
+    flags = np.where(rng.uniform(size=nb) < post_physics, 0x1000, 0).astype(np.uint16)
+    return rest, parent, level, flags
+
+
+def make_bone_keys(names, seed: int, keys_per: int = 6, span: int = 240, curved: float = 0.7):
+    """VMD bone records (name, frame, t, q, interpolation[64]) for simple_mmd_renderer_amd.vmd.write_vmd.
+    Rotations are unit quaternions from both hemispheres (NLerp's sign flip), a few left un-normalised;
+    `curved` is the fraction of keys with random Bezier control bytes (the rest keep the linear default)."""
+    rng = np.random.RandomState(seed)
+    keys = []
+    for n in names:
+        for f in sorted(rng.choice(span, keys_per, replace=False)):
+            q = rng.normal(size=4)
+            q = q / np.linalg.norm(q) * (1.0 if rng.uniform() < 0.9 else rng.uniform(0.5, 1.5))
+            t = rng.uniform(-2, 2, 3)
+            ip = None
+            if rng.uniform() < curved:
+                ip = rng.randint(0, 128, 64).astype(np.uint8)
+                if rng.uniform() < 0.2:                      # one channel exactly linear (x == y)
+                    c = 16 * rng.randint(0, 4)
+                    ip[c + 4], ip[c + 12] = ip[c + 0], ip[c + 8]
+                ip = bytes(ip)
+            keys.append((n, int(f), tuple(np.float32(t).tolist()), tuple(np.float32(q).tolist()), ip))
+    return keys

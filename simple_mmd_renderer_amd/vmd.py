@@ -115,6 +115,9 @@ class Vmd:
     def bind_morphs(self, morph_names: Sequence[str]) -> "MorphMotion":
         return MorphMotion(self, morph_names)
 
+    def bind_bones(self, bone_names: Sequence[str]) -> "BoneMotion":
+        return BoneMotion(self, bone_names)
+
 
 class MorphMotion:
     """Morph tracks of a motion bound to a model's morph list; evaluated on the GPU."""
@@ -144,6 +147,105 @@ class MorphMotion:
     def close(self):
         if getattr(self, "h", None):
             api.lib().mmdx_morph_motion_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+FRAMES_ON_DEVICE = 1 << 0
+POSES_ON_DEVICE = 1 << 1
+POSE_FLOATS = 8
+
+
+class BoneMotion:
+    """Bone tracks of a motion bound to a model's bone list; local poses are evaluated on the GPU
+    (Motion::GetBonePose for every (instance, bone): t.xyz, 0, q.xyzw)."""
+
+    def __init__(self, vmd: Vmd, bone_names: Sequence[str]):
+        enc = [n.encode("utf-8") for n in bone_names]
+        arr = (C.c_char_p * max(len(enc), 1))(*enc)
+        self.h = C.c_void_p()
+        api.check(api.lib().mmdx_vmd_bind_bones(vmd.h, len(enc), arr, C.byref(self.h)))
+        nb, mapped, keys, curves = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        api.check(api.lib().mmdx_bone_motion_get_info(self.h, C.byref(nb), C.byref(mapped), C.byref(keys),
+                                                      C.byref(curves)))
+        self.nb, self.n_mapped, self.n_keys, self.n_curves = nb.value, mapped.value, keys.value, curves.value
+
+    def eval(self, frames, model=None) -> np.ndarray:
+        """Host convenience: frames [NI] -> poses f32 [NI, NB, 8] (device evaluation + D2H)."""
+        fr = np.ascontiguousarray(frames, np.uint32).reshape(-1)
+        out = np.empty((fr.size, self.nb, POSE_FLOATS), np.float32)
+        api.check(api.lib().mmdx_bone_motion_eval(self.h, model.h if model is not None else None, fr.size,
+                                                  fr.ctypes.data, 0, out.ctypes.data))
+        return out
+
+    def eval_device(self, n_instances: int, frames_ptr, out_ptr, model=None) -> None:
+        """frames u32[NI] and out f32[NI][NB][8] resident in HBM; asynchronous on the model's stream."""
+        api.check(api.lib().mmdx_bone_motion_eval(self.h, model.h if model is not None else None, n_instances,
+                                                  frames_ptr, FRAMES_ON_DEVICE | api.OUT_ON_DEVICE, out_ptr))
+
+    def close(self):
+        if getattr(self, "h", None):
+            api.lib().mmdx_bone_motion_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SkeletonDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_bones", C.c_uint32), ("rest_position", C.c_void_p),
+                ("parent", C.c_void_p), ("transform_level", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class SkeletonInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_bones", C.c_uint32), ("n_pre_physics", C.c_uint32),
+                ("n_post_physics", C.c_uint32), ("max_chain", C.c_uint32), ("reserved0", C.c_uint32)]
+
+
+class Skeleton:
+    """A model's bone hierarchy compiled for the device bone solve (local poses -> float[16] palettes,
+    Poser::UpdateBoneTransform + UpdateBoneSkinningMatrix in the reference's evaluation order)."""
+
+    def __init__(self, rest_position, parent, transform_level=None, flags=None):
+        rest = np.ascontiguousarray(rest_position, np.float32).reshape(-1, 3)
+        nb = rest.shape[0]
+        par = np.ascontiguousarray(parent, np.int32).reshape(nb)
+        lvl = np.ascontiguousarray(transform_level, np.int32).reshape(nb) if transform_level is not None else None
+        flg = np.ascontiguousarray(flags, np.uint16).reshape(nb) if flags is not None else None
+        d = SkeletonDesc(C.sizeof(SkeletonDesc), nb, rest.ctypes.data, par.ctypes.data,
+                         lvl.ctypes.data if lvl is not None else None, flg.ctypes.data if flg is not None else None)
+        self.h = C.c_void_p()
+        api.check(api.lib().mmdx_skeleton_create(C.byref(d), C.byref(self.h)))
+        info = SkeletonInfo()
+        info.struct_size = C.sizeof(SkeletonInfo)
+        api.check(api.lib().mmdx_skeleton_get_info(self.h, C.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in SkeletonInfo._fields_}
+        self.nb = nb
+
+    def solve(self, poses, model=None) -> np.ndarray:
+        """Host convenience: poses f32 [NI, NB, 8] -> palettes f32 [NI, NB, 16]."""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, self.nb, POSE_FLOATS)
+        out = np.empty((p.shape[0], self.nb, 16), np.float32)
+        api.check(api.lib().mmdx_skeleton_solve(self.h, model.h if model is not None else None, p.shape[0],
+                                                p.ctypes.data, 0, out.ctypes.data))
+        return out
+
+    def solve_device(self, n_instances: int, poses_ptr, out_ptr, model=None) -> None:
+        """poses and palettes resident in HBM; asynchronous on the model's stream."""
+        api.check(api.lib().mmdx_skeleton_solve(self.h, model.h if model is not None else None, n_instances,
+                                                poses_ptr, POSES_ON_DEVICE | api.OUT_ON_DEVICE, out_ptr))
+
+    def close(self):
+        if getattr(self, "h", None):
+            api.lib().mmdx_skeleton_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,230 @@
+"""Bone tracks -> local poses -> bone palette.
+
+CPU tests pin the C restatement (oracle/mmdx_oracle.c: mmdx_oracle_bone_pose / _bone_solve) against the
+real libmmd and against the committed golden fixture, and cover the host-side compilation behind
+mmdx_vmd_bind_bones / mmdx_skeleton_create.  GPU tests compare the HIP kernels with the oracle and the
+fixture through the C ABI: bit-exact, no tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import Reference, ReferenceMotion, reference_available
+from simple_mmd_renderer_amd import _capi as api
+from simple_mmd_renderer_amd import synth, vmd
+from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer
+from tests import golden_util as gu
+
+BONES = ["センター", "上半身", "首", "頭", "左腕", "左ひじ", "右腕", "右ひじ", "BoneEN"]
+DEFAULT_IP = bytes([20, 20, 0, 0, 20, 20, 20, 20, 107, 107, 107, 107, 107, 107, 107, 107] * 4)
+
+
+@pytest.fixture(autouse=True)
+def _lib(hip_lib):
+    return hip_lib
+
+
+def tracks_of(v):
+    """name -> (frames, tr, rot, interp) of a parsed motion (after 'last record wins')."""
+    out = {}
+    for i, n in enumerate(v.bone_track_names):
+        ks = v.bone_track(i)
+        out[n] = (np.array([k["frame"] for k in ks], np.uint32),
+                  np.array([k["translation"] for k in ks], np.float32).reshape(-1, 3),
+                  np.array([k["rotation"] for k in ks], np.float32).reshape(-1, 4),
+                  np.frombuffer(b"".join(k["interpolation"] for k in ks), np.uint8).view(np.int8).reshape(-1, 64))
+    return out
+
+
+def oracle_poses(oracle, v, model_bones, frames):
+    tr = tracks_of(v)
+    out = np.zeros((len(frames), len(model_bones), 8), np.float32)
+    for j, n in enumerate(model_bones):
+        t = tr.get(n)
+        for i, f in enumerate(frames):
+            out[i, j] = oracle.bone_pose(*t, f) if t is not None else oracle.bone_pose([], [], [], [], f)
+    return out
+
+
+def random_poses(ni, nb, seed):
+    rng = np.random.RandomState(seed)
+    p = np.zeros((ni, nb, 8), np.float32)
+    p[..., 0:3] = rng.uniform(-1.5, 1.5, (ni, nb, 3))
+    q = rng.normal(size=(ni, nb, 4))
+    p[..., 4:8] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    p[0, 0, 4:8] = (0, 0, 0, 1)
+    p[0, 0, 0:3] = (-0.0, 0.0, 1e-39)          # -0 and a denormal through "0 + t"
+    return p
+
+
+# ---------------------------------------------------------------------------------------- CPU ----
+def test_golden_rig_oracle(oracle):
+    """tests/golden/rig_small.vmd: libmmd's Motion::GetBonePose and bone-solve answers, recorded."""
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "rig_small_expect.npz"))
+    v = vmd.Vmd(os.path.join(gu.GOLDEN_DIR, "rig_small.vmd"))
+    names = [str(n) for n in z["model_bone_names"]]
+    poses = oracle_poses(oracle, v, names, z["frames"])
+    gu.assert_bits_equal(poses, z["expect_poses"], "poses")
+    for i in range(len(z["frames"])):
+        pal = oracle.bone_solve(z["rest"], z["parent"], z["expect_poses"][i], z["level"], z["flags"])
+        gu.assert_bits_equal(pal, z["expect_palettes"][i], f"palette of frame {z['frames'][i]}")
+    assert len(set(bytes(k) for k in tracks_of(v)[names[0]][3])) > 1   # the fixture has curved keys
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_oracle_bone_pose_vs_reference(oracle, tmp_path, seed):
+    keys = synth.make_bone_keys(BONES, seed, keys_per=5 + seed, span=150)
+    keys.append((BONES[2], keys[3][1] if keys[3][0] == BONES[2] else 7, (1, 2, 3), (0, 0, 0, 1), None))
+    keys.append((BONES[0], 2 ** 24 + 9, (0, 1, 0), (0, 0.6, 0, 0.8), bytes([64] * 64)))   # frames beyond float's exact range
+    np.random.RandomState(seed).shuffle(keys)
+    p = tmp_path / "b.vmd"
+    p.write_bytes(vmd.write_vmd(keys, []))
+    v = vmd.Vmd(str(p))
+    rm = ReferenceMotion(str(p))
+    at = np.r_[np.arange(0, 160), 2 ** 24 + np.arange(0, 12), 4_000_000_000].astype(np.uint32)
+    got = oracle_poses(oracle, v, BONES, at)
+    for j, n in enumerate(BONES):
+        want = np.stack([rm.bone_pose(n.encode("shift_jis"), int(f)) for f in at])
+        gu.assert_bits_equal(got[:, j], want, f"track {n}")
+    assert rm.bone_pose("無い".encode("shift_jis"), 3) is None
+    rm.close()
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
+def test_reference_curves_are_not_degenerate(tmp_path):
+    """The oracle harness mirrors the viewer's include order, so libmmd's Bezier bisection uses the
+    floating-point abs (see oracle/ref_harness.cpp): an S-shaped curve must not evaluate to a constant."""
+    ip = bytearray(DEFAULT_IP)
+    ip[0], ip[4], ip[8], ip[12] = 20, 100, 90, 30            # x channel
+    keys = [("センター", 0, (0, 0, 0), (0, 0, 0, 1), bytes(ip)), ("センター", 100, (10, 10, 10), (0, 0, 0, 1), None)]
+    p = tmp_path / "c.vmd"
+    p.write_bytes(vmd.write_vmd(keys, []))
+    rm = ReferenceMotion(str(p))
+    xs = [float(rm.bone_pose("センター".encode("shift_jis"), f)[0]) for f in (10, 50, 90)]
+    ys = [float(rm.bone_pose("センター".encode("shift_jis"), f)[1]) for f in (10, 50, 90)]
+    rm.close()
+    assert ys == [1.0, 5.0, 9.0]                             # linear channel
+    assert xs[0] < xs[1] < xs[2] and abs(xs[0] - 1.0) > 0.5  # curved channel: monotone, far from linear
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
+@pytest.mark.parametrize("nb,fwd,post,levels,seed", [(1, 0, 0.0, 1, 0), (7, 0, 0.0, 1, 1), (40, 5, 0.25, 3, 2),
+                                                     (120, 12, 0.5, 4, 3), (33, 30, 1.0, 2, 4)])
+def test_oracle_bone_solve_vs_reference(oracle, nb, fwd, post, levels, seed):
+    rest, parent, level, flags = synth.make_skeleton(nb, seed, fwd, post, levels)
+    if seed == 3:
+        level[5] = -1                                        # (size_t) of a negative level sorts last
+    ref = Reference.skeleton(rest, parent, level, flags)
+    for i, poses in enumerate(random_poses(3, nb, seed)):
+        gu.assert_bits_equal(oracle.bone_solve(rest, parent, poses, level, flags), ref.solve(poses), f"palette {i}")
+    ref.close()
+
+
+def test_bind_bones_host_side():
+    keys = synth.make_bone_keys(BONES[:4], 5, keys_per=4, curved=1.0)
+    v = vmd.Vmd(vmd.write_vmd(keys, []))
+    bm = v.bind_bones([BONES[1], "無い", BONES[0], BONES[3]])
+    assert (bm.nb, bm.n_mapped, bm.n_keys) == (4, 3, 12)
+    assert 0 < bm.n_curves <= 12 * 4
+    lin = vmd.Vmd(vmd.write_vmd([(BONES[0], 0, (0, 0, 0), (0, 0, 0, 1), None),
+                                 (BONES[0], 9, (1, 0, 0), (0, 0, 0, 1), None)], [])).bind_bones(BONES[:1])
+    assert (lin.n_keys, lin.n_curves) == (2, 0)              # the default interpolation is linear: no table
+    empty = v.bind_bones([])
+    assert (empty.nb, empty.n_keys) == (0, 0)
+
+
+def test_skeleton_create_host_side():
+    rest, parent, level, flags = synth.make_skeleton(50, 1, 6, 0.3, 3)
+    sk = vmd.Skeleton(rest, parent, level, flags)
+    assert sk.info["n_bones"] == 50 and sk.info["n_pre_physics"] + sk.info["n_post_physics"] == 50
+    assert 1 <= sk.info["max_chain"] <= 51
+    for bad in (0x0020, 0x0100, 0x0200):
+        f2 = flags.copy()
+        f2[7] |= bad
+        with pytest.raises(api.MmdxError) as e:
+            vmd.Skeleton(rest, parent, level, f2)
+        assert e.value.status == 6
+    p2 = parent.copy()
+    p2[9] = 9
+    with pytest.raises(api.MmdxError) as e:
+        vmd.Skeleton(rest, p2, level, flags)
+    assert e.value.status == 1 and "own parent" in str(e.value)
+    p3 = parent.copy()
+    p3[3] = 1000                                             # out of range = no parent, as in the reference
+    assert vmd.Skeleton(rest, p3).info["n_bones"] == 50
+
+
+# ---------------------------------------------------------------------------------------- GPU ----
+@pytest.mark.gpu
+def test_gpu_golden_rig():
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "rig_small_expect.npz"))
+    v = vmd.Vmd(os.path.join(gu.GOLDEN_DIR, "rig_small.vmd"))
+    names = [str(n) for n in z["model_bone_names"]]
+    bm = v.bind_bones(names)
+    poses = bm.eval(z["frames"])
+    gu.assert_bits_equal(poses, z["expect_poses"], "poses")
+    sk = vmd.Skeleton(z["rest"], z["parent"], z["level"], z["flags"])
+    gu.assert_bits_equal(sk.solve(poses), z["expect_palettes"], "palettes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gpu_bone_motion_vs_oracle(oracle, seed):
+    names = [f"bone{i}" for i in range(40)]
+    keys = synth.make_bone_keys(names[:33], 10 + seed, keys_per=3 + 4 * seed, span=400)
+    keys.append((names[0], 2 ** 24 + 9, (0, 1, 0), (0, 0.6, 0, 0.8), bytes([64] * 64)))
+    v = vmd.Vmd(vmd.write_vmd(keys, []))
+    at = np.r_[np.arange(0, 420, 1 + seed), 2 ** 24 + np.arange(0, 12), 4_000_000_000].astype(np.uint32)
+    got = v.bind_bones(names).eval(at)
+    gu.assert_bits_equal(got, oracle_poses(oracle, v, names, at), "poses")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,fwd,post,levels,seed", [(1, 0, 0.0, 1, 0), (40, 5, 0.25, 3, 2), (300, 20, 0.3, 4, 3),
+                                                     (33, 30, 1.0, 2, 4), (2048, 100, 0.1, 5, 5)])
+def test_gpu_skeleton_vs_oracle(oracle, nb, fwd, post, levels, seed):
+    rest, parent, level, flags = synth.make_skeleton(nb, seed, fwd, post, levels)
+    poses = random_poses(5, nb, seed)
+    got = vmd.Skeleton(rest, parent, level, flags).solve(poses)
+    for i in range(poses.shape[0]):
+        gu.assert_bits_equal(got[i], oracle.bone_solve(rest, parent, poses[i], level, flags), f"palette {i}")
+
+
+@pytest.mark.gpu
+def test_gpu_motion_to_vertices_all_on_device(oracle):
+    """VMD -> local poses -> palettes -> skinned vertices without leaving HBM, against the oracle run
+    step by step on the host: the palette producer feeds mmdx_deform_batched bit-exactly."""
+    m = synth.make_model(3000, 48, 6, 200, seed=21)
+    names = [f"b{i}" for i in range(m.nb)]
+    mnames = [f"m{i}" for i in range(m.nm)]
+    rng = np.random.RandomState(4)
+    v = vmd.Vmd(vmd.write_vmd(synth.make_bone_keys(names[:40], 8, keys_per=5, span=120),
+                              [(n, int(f), float(np.float32(rng.uniform(0, 1)))) for n in mnames for f in (0, 50, 110)]))
+    parent = np.asarray(m.bone_parent, np.int32)
+    sk = vmd.Skeleton(m.bone_pos, parent)
+    bm, mm = v.bind_bones(names), v.bind_morphs(mnames)
+    ni = 37
+    frames = (np.arange(ni) * 3 + 1).astype(np.uint32)
+    dm = DeformModel(m)
+    d_fr = DeviceBuffer.from_numpy(frames)
+    d_pose, d_pal = DeviceBuffer(ni * m.nb * 32), DeviceBuffer(ni * m.nb * 64)
+    d_w = DeviceBuffer(ni * m.nm * 4)
+    sa, sb = dm.out_sizes(api.OUT_SOA, ni)
+    d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+    bm.eval_device(ni, d_fr.ptr, d_pose.ptr, dm)
+    sk.solve_device(ni, d_pose.ptr, d_pal.ptr, dm)
+    mm.eval_device(ni, d_fr.ptr, d_w.ptr, dm)
+    dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA,
+                          api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE)
+    dm.sync()
+    pos = d_a.download((ni, m.nv, 3), np.float32)
+    nrm = d_b.download((ni, m.nv, 3), np.float32)
+    poses = oracle_poses(oracle, v, names, frames)
+    rates = mm.eval(frames)
+    for i in range(ni):
+        pal = oracle.bone_solve(m.bone_pos, parent.astype(np.int64), poses[i])
+        want_p, want_n = oracle.deform(m, rates[i], pal)
+        gu.assert_bits_equal(pos[i], want_p, f"positions of instance {i}")
+        gu.assert_bits_equal(nrm[i], want_n, f"normals of instance {i}")
