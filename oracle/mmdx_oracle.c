@@ -24,6 +24,7 @@
  * Matrix convention: row vector, row-major float[16], translation in elements 12..14
  *   (L/util/math.inl:383-395).
  */
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -252,8 +253,6 @@ static float curve_eval(const curve_t *cv, float x) {
     if (ix < 31) return (1.0f - r) * cv->pre[ix] + r * cv->pre[ix + 1];
     return cv->pre[31];
 }
-
-extern double sqrt(double);
 
 /* One bone track: frames[n] ascending, tr[n][3], rot[n][4], interp[n][64]; out = t.xyz, 0, q.xyzw.
  * n == 0: the pose ResetPosing leaves (zero translation, identity rotation). */

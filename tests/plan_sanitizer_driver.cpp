@@ -7,6 +7,8 @@
 #include <vector>
 
 #include "../simple_mmd_renderer_amd/csrc/plan.hpp"
+#include "../simple_mmd_renderer_amd/csrc/rig.hpp"
+#include "../simple_mmd_renderer_amd/csrc/vmd.hpp"
 
 int main() {
     std::mt19937 rng(1234);
@@ -146,9 +148,43 @@ int main() {
         for (int k = 0; k < nmut; ++k) g[rng() % g.size()] = uint8_t(rng());
         if (it % 7 == 0) g.resize(rng() % g.size());
         vmd = nullptr;
-        if (mmdx_vmd_parse(g.data(), g.size(), &vmd) == MMDX_OK) { ++ok; mmdx_vmd_destroy(vmd); } else ++bad;
+        if (mmdx_vmd_parse(g.data(), g.size(), &vmd) == MMDX_OK) {
+            ++ok;
+            // bone tracks of whatever parsed: curve presampling + binding (rig.cpp)
+            const mmdx::VmdBoneTracks t = mmdx::vmd_bone_tracks(vmd);
+            const char *bn[3] = {"bone", nullptr, "x"};
+            mmdx::BoneMotionHost bm;
+            mmdx::build_bone_motion(*t.names, *t.off, t.keys, 3, bn, bm);
+            if (bm.key_off.size() != 4 || bm.key_curve.size() != bm.key_frame.size() * 4) return 8;
+            mmdx_vmd_destroy(vmd);
+        } else ++bad;
     }
     std::printf("vmd fuzz: parsed=%d rejected=%d\n", ok, bad);
+
+    // skeleton compile (rig.cpp): random hierarchies incl. forward / out-of-range / self parents
+    int sk_ok = 0, sk_bad = 0;
+    for (int it = 0; it < 300; ++it) {
+        const uint32_t nb = rng() % 70;
+        std::vector<float> rest(size_t(nb) * 3 + 1, 1.0f);
+        std::vector<int32_t> par(nb + 1), lvl(nb + 1);
+        std::vector<uint16_t> fl(nb + 1);
+        for (uint32_t b = 0; b < nb; ++b) {
+            par[b] = int32_t(rng() % (nb + 4)) - 2;
+            lvl[b] = int32_t(rng() % 4) - 1;
+            fl[b] = rng() % 5 == 0 ? 0x1000 : 0;
+        }
+        mmdx_skeleton_desc d{};
+        d.struct_size = sizeof(d); d.n_bones = nb;
+        d.rest_position = rest.data(); d.parent = par.data();
+        d.transform_level = it % 3 ? lvl.data() : nullptr; d.flags = it % 2 ? fl.data() : nullptr;
+        mmdx::SkeletonPlan sp;
+        if (mmdx::build_skeleton(d, sp).empty()) {
+            ++sk_ok;
+            if (sp.chain_off.size() != size_t(nb) + 1 || sp.chain_off.back() != sp.chain.size()) return 9;
+            for (uint32_t c : sp.chain) if (c != mmdx::kIdentityParent && c >= nb) return 10;
+        } else ++sk_bad;
+    }
+    std::printf("skeleton: compiled=%d rejected=%d\n", sk_ok, sk_bad);
     return 0;
 }
 

@@ -17,6 +17,7 @@ def test_plan_builder_under_asan_ubsan(tmp_path):
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "plan.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "pmx.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "vmd.cpp"),
+                                         os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "rig.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "error.cpp"),
                                          "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -38,6 +39,8 @@ void mmdx_oracle_morph(uint32_t, uint32_t, const int32_t*, const uint32_t*, cons
 void mmdx_oracle_skin(uint32_t, const float*, const float*, const float*, const int32_t*, const int64_t*, const float*, const float*, float*, float*);
 void mmdx_oracle_normalize(uint32_t, int32_t*, int64_t*, float*, const int64_t*);
 void mmdx_oracle_repack32(uint32_t, const float*, const float*, const float*, float, float*);
+void mmdx_oracle_bone_pose(uint32_t, const uint32_t*, const float*, const float*, const int8_t*, uint32_t, float*);
+int mmdx_oracle_bone_solve(uint32_t, const float*, const int64_t*, const int32_t*, const uint16_t*, const float*, float*, void*);
 int main(void) {
   enum { NV = 1000, NB = 20, NM = 4, K = 50 };
   float *pos = malloc(NV*12), *nrm = malloc(NV*12), *uv = malloc(NV*8), *w = malloc(NV*16), *pal = malloc(NB*64);
@@ -62,7 +65,7 @@ int main(void) {
 }
 ''')
     exe = tmp_path / "oracle_san"
-    cmd = ["gcc", "-std=gnu11"] + SAN + [str(drv), os.path.join(ROOT, "oracle", "mmdx_oracle.c"), "-o", str(exe)]
+    cmd = ["gcc", "-std=gnu11"] + SAN + [str(drv), os.path.join(ROOT, "oracle", "mmdx_oracle.c"), "-o", str(exe), "-lm"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
