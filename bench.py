@@ -263,6 +263,52 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     for b in (d_pal, d_w, d_a, d_b):
         b.free()
 
+    # The palette producer for the crowd: a 300-track bone motion with Bezier curves
+    # -> local poses -> FK palettes for 1024 instances at their own frames, all in HBM; then the whole
+    # motion -> vertices step (poses + palettes + morph pass + deform).  CPU: libmmd doing the same bone
+    # work per instance (GetBonePose/SetBonePose per bone + Pre/PostPhysicsPosing), one thread.
+    try:
+        from simple_mmd_renderer_amd import vmd as vmdmod
+        ni = 1024
+        names = [f"b{i}" for i in range(model3.nb)]
+        vm = vmdmod.Vmd(vmdmod.write_vmd(synth.make_bone_keys(names, 303, keys_per=20, span=600), []))
+        bm = vm.bind_bones(names)
+        sk = vmdmod.Skeleton(model3.bone_pos, np.asarray(model3.bone_parent, np.int32))
+        fr_i = ((np.arange(ni) * 7) % 600).astype(np.uint32)
+        d_fr = DeviceBuffer.from_numpy(fr_i)
+        d_pose, d_pal = DeviceBuffer(ni * model3.nb * 32), DeviceBuffer(ni * model3.nb * 64)
+        d_w = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, 3))
+        sa, sb = dm3.out_sizes(api.OUT_SOA, ni)
+        d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+
+        def producer():
+            bm.eval_device(ni, d_fr.ptr, d_pose.ptr, dm3)
+            sk.solve_device(ni, d_pose.ptr, d_pal.ptr, dm3)
+
+        def whole():
+            producer()
+            dm3.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags_dev | api.WEIGHTS_SHARED)
+        ms_p, ms_w = time_calls(dm3, producer, 50), time_calls(dm3, whole, 20)
+        c = {"instances": ni, "bones": model3.nb, "bone_keys": bm.n_keys, "curve_tables": bm.n_curves,
+             "gpu_ms_poses_plus_palettes": ms_p, "gpu_palettes_per_s": ni * model3.nb / (ms_p * 1e-3),
+             "gpu_ms_motion_to_vertices": ms_w, "gpu_vertices_per_s": ni * model3.nv / (ms_w * 1e-3)}
+        from oracle.pyoracle import Reference, ReferenceMotion, reference_available   # checker, CPU leg only
+        if reference_available():
+            import tempfile
+            path = os.path.join(tempfile.mkdtemp(prefix="mmdx_"), "crowd.vmd")
+            open(path, "wb").write(vmdmod.write_vmd(synth.make_bone_keys(names, 303, keys_per=20, span=600), []))
+            rmot = ReferenceMotion(path)
+            rsk = Reference.skeleton(model3.bone_pos, np.asarray(model3.bone_parent, np.int64))
+            secs = rmot.time_motion_solve(rsk, fr_i[:256]) * (ni / 256)
+            c.update({"cpu_reference_ms_poses_plus_palettes": secs * 1e3,
+                      "cpu_reference_palettes_per_s": ni * model3.nb / secs})
+            rmot.close(); rsk.close()
+        out["config3_motion_to_palettes"] = c
+        for b in (d_fr, d_pose, d_pal, d_w, d_a, d_b):
+            b.free()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["config3_motion_to_palettes"] = {"error": repr(e)}
+
     # config 1: 20k verts / 150 bones / 30 morphs, 600 frames -- the reference's own CPU-runnable case.
     # GPU: the 600 frames as 6 batched calls of 100 (per-frame morph weights, fused gather), interleaved
     # 32-byte output incl. the 0.1 scale = Deform + UpdateDeformedVertices.  CPU: libmmd's whole frame

@@ -194,6 +194,13 @@ class ReferenceMotion:
         ok = self.lib.mmdref_motion_bone_pose(self.h, sjis_name, C.c_uint32(frame), _p(out, C.c_float))
         return out if ok else None
 
+    def time_motion_solve(self, skeleton_ref: "Reference", frames) -> float:
+        """Seconds libmmd needs to turn this motion into palettes for len(frames) instances of a
+        Reference.skeleton whose bone b is keyed "b<b>" (GetBonePose + SetBonePose + Pre/PostPhysicsPosing)."""
+        fr = _c(frames, np.uint32).reshape(-1)
+        self.lib.mmdref_time_motion_solve.restype = C.c_double
+        return float(self.lib.mmdref_time_motion_solve(self.h, skeleton_ref.h, C.c_uint32(fr.size), _p(fr, C.c_uint32)))
+
     def names_match_model(self, ref_model: "Reference") -> int:
         """How many of the model's morph names libmmd finds in the motion (MotionPlayer's mapping)."""
         return int(self.lib.mmdref_motion_count_registered_morphs(self.h, ref_model.h))

@@ -307,6 +307,27 @@ void *mmdref_create_skeleton(uint32_t nb, const float *bone_pos, const int64_t *
     return r;
 }
 
+// CPU baseline of the palette producer: per instance MotionPlayer::SeekFrame's bone half
+// (GetBonePose + SetBonePose per mapped bone, poser_impl.inl:543-547) + Pre/PostPhysicsPosing.
+// Bone b of the skeleton is looked up under the Shift-JIS name "b<b>".  Returns seconds.
+double mmdref_time_motion_solve(void *motion, void *ref, uint32_t instances, const uint32_t *frames) {
+    mmd::Motion *m = static_cast<mmd::Motion *>(motion);
+    Ref *r = static_cast<Ref *>(ref);
+    const size_t nb = r->model.GetBoneNum();
+    std::vector<std::pair<std::wstring, size_t>> map;
+    for (size_t b = 0; b < nb; ++b) {
+        const std::wstring key = mmd::ShiftJISToUTF16String("b" + std::to_string(b));
+        if (m->IsBoneRegistered(key)) map.push_back(std::make_pair(key, b));
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < instances; ++i) {
+        for (const auto &kv : map) r->poser->SetBonePose(kv.second, m->GetBonePose(kv.first, size_t(frames[i])));
+        r->poser->PrePhysicsPosing();
+        r->poser->PostPhysicsPosing();
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void mmdref_destroy(void *h) { delete static_cast<Ref *>(h); }
 
 // Skin tags after the optional Normalize() -- lets tests check the load-time retagging.
