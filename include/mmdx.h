@@ -368,17 +368,38 @@ typedef struct mmdx_skeleton_desc {           /* e.g. straight from mmdx_pmx_get
     const int32_t *transform_level;           /* [n_bones] or NULL (all 0); compared as unsigned, like
                                                  the reference's size_t cast                          */
     const uint16_t *flags;                    /* [n_bones] PMX bone flag word, or NULL (all 0)        */
+    /* append (inherit) bones -- read where flags has MMDX_BONE_APPEND_*; NULL if no bone has them     */
+    const int32_t *append_parent;             /* [n_bones]; outside [0, n_bones) = the bone does not
+                                                 append (L/motion/poser_impl.inl:50-56)               */
+    const float *append_ratio;                /* [n_bones]                                            */
+    /* CCD-IK -- read where flags has MMDX_BONE_HAS_IK; NULL if no bone has it                         */
+    const int32_t *ik_target;                 /* [n_bones]                                            */
+    const int32_t *ik_loop_count;             /* [n_bones]; negative or > 256 means 256 (:94)         */
+    const float *ik_angle_limit;              /* [n_bones] radians per link step                      */
+    const uint32_t *ik_link_offset;           /* [n_bones+1] into the link arrays                     */
+    const int32_t *ik_link_bone;              /* [L] target-side link first                           */
+    const uint8_t *ik_link_limited;           /* [L]                                                  */
+    const float *ik_link_lo, *ik_link_hi;     /* [L][3] Euler limits (either order; min/max is taken) */
 } mmdx_skeleton_desc;
 
 typedef struct mmdx_skeleton_info {
     uint32_t struct_size;
     uint32_t n_bones, n_pre_physics, n_post_physics;
-    uint32_t max_chain;                       /* longest parent chain evaluated per bone              */
+    uint32_t max_chain;                       /* longest parent chain (parallel solver), else 0       */
+    uint32_t solver;                          /* MMDX_SOLVER_*                                        */
+    uint32_t n_ik_bones, n_ik_links, n_append_bones;
     uint32_t reserved0;
 } mmdx_skeleton_info;
 
-/* MMDX_ERR_UNSUPPORTED for skeletons with IK or append (inherit) bones: those need the reference's
- * serial solve (CCD-IK through double-precision libm) and stay on the host this round. */
+enum {
+    MMDX_SOLVER_PARALLEL_FK = 0,  /* no IK / append: one thread per (instance, bone), bit-exact      */
+    MMDX_SOLVER_SERIAL = 1        /* IK / append present: the reference's in-order sweep, one thread
+                                     per instance; sin/cos/asin/acos/atan2 through the device's double
+                                     libm like the reference's through the host's     */
+};
+
+/* Index validation happens here (MMDX_ERR_BAD_INDEX), so solve cannot read out of range.
+ * MMDX_ERR_UNSUPPORTED: an IK link or target that is itself an IK bone (the reference would recurse). */
 MMDX_API mmdx_status mmdx_skeleton_create(const mmdx_skeleton_desc *desc, mmdx_skeleton_t *out_skeleton);
 MMDX_API mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t skeleton, mmdx_skeleton_info *info);
 /* out_palettes[i][b][16] from poses[i][b][MMDX_POSE_FLOATS].  flags: MMDX_POSES_ON_DEVICE |

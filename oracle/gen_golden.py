@@ -357,6 +357,21 @@ def main():
                         expect_palettes=pals)
     print(f"{'rig_small.vmd':28s} {len(rdata) / 1024:7.1f} KB + expectations")
 
+    # IK fixture: rigs with CCD-IK chains and append bones -> libmmd's palettes for random local poses.
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(48, seed=95, n_ik=4, n_append=5)
+    rng_ik = np.random.RandomState(96)
+    poses = np.zeros((12, 48, 8), np.float32)
+    poses[..., 0:3] = rng_ik.uniform(-1.5, 1.5, (12, 48, 3))
+    qq = rng_ik.normal(size=(12, 48, 4))
+    poses[..., 4:8] = qq / np.linalg.norm(qq, axis=-1, keepdims=True)
+    rsk = Reference.skeleton(rest, parent, level, flags, ap, ar, ik)
+    pals = np.stack([rsk.solve(poses[i]) for i in range(poses.shape[0])])
+    rsk.close()
+    np.savez_compressed(os.path.join(OUT, "rig_ik_expect.npz"), rest=rest, parent=parent, level=level, flags=flags,
+                        append_parent=ap, append_ratio=ar, poses=poses, expect_palettes=pals,
+                        **{"ik_" + k: v for k, v in ik.items()})
+    print(f"{'rig_ik_expect.npz':28s} 48 bones, {int((flags & 0x20).astype(bool).sum())} IK chains, 12 poses")
+
     # G13 config-1 plumbing: 20 000 verts / 150 bones / 30 morphs / 600 frames, checksums only.
     cfg = synth.CONFIGS["config1_20k"]
     m = synth.make_config("config1_20k")

@@ -386,6 +386,325 @@ int mmdx_oracle_bone_solve(uint32_t nb, const float *rest, const int64_t *parent
     return 0;
 }
 
+/* ---- full bone solve: append (inherit) bones and CCD-IK (Poser ctor L/motion/poser_impl.inl:47-97,
+ * Poser::UpdateBoneTransform :142-310, PrePhysicsPosing reset :366-377, Pre/PostPhysicsPosing :384-394).
+ * Transcendentals go through double libm and back to float exactly like L/util/math.inl:27-45.  Bone
+ * morphs are not an input here (morph_rotation_ = identity, morph_translation_ = 0).
+ * `abs` in the ctor's limit classification is the float overload (include-order note in ref_harness). */
+typedef struct { float i, j, k, e; } quat_t;
+typedef struct {
+    quat_t total_rot, ik_rot, pre_ik_rot;
+    float total_tr[3], local[16];
+} bone_state_t;
+
+typedef struct {
+    uint32_t nb;
+    const float *rest;
+    const int64_t *parent, *append_parent, *ik_target, *ik_link_bone;
+    const uint16_t *flags;
+    const float *append_ratio, *ik_angle, *ik_link_lo, *ik_link_hi;
+    const int32_t *ik_loop;
+    const uint32_t *ik_link_off;
+    const uint8_t *ik_link_limited, *is_ik_link;
+    const float *poses;
+    bone_state_t *st;
+} solve_ctx;
+
+enum { FIX_NONE = 0, FIX_X, FIX_Y, FIX_Z, FIX_ALL };
+enum { ORDER_ZXY = 0, ORDER_XYZ, ORDER_YZX };
+
+static float f_sqrt(float x) { return (float)sqrt((double)x); }
+static float f_sin(float x) { return (float)sin((double)x); }
+static float f_cos(float x) { return (float)cos((double)x); }
+static float f_asin(float x) { return (float)asin((double)x); }
+static float f_acos(float x) { return (float)acos((double)x); }
+static float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+static quat_t q_identity(void) { quat_t q = {0.0f, 0.0f, 0.0f, 1.0f}; return q; }
+static quat_t q_mul(quat_t a, quat_t q) {                  /* L/util/math_impl.inl:510-517 */
+    quat_t r;
+    r.i = (a.e * q.i + a.i * q.e + a.j * q.k) - a.k * q.j;
+    r.j = (a.e * q.j + a.j * q.e + a.k * q.i) - a.i * q.k;
+    r.k = (a.e * q.k + a.i * q.j + a.k * q.e) - a.j * q.i;
+    r.e = a.e * q.e - (a.i * q.i + a.j * q.j + a.k * q.k);
+    return r;
+}
+static quat_t q_scale(quat_t a, float s) { quat_t r = {a.i * s, a.j * s, a.k * s, a.e * s}; return r; }
+static quat_t q_add(quat_t a, quat_t b) { quat_t r = {a.i + b.i, a.j + b.j, a.k + b.k, a.e + b.e}; return r; }
+static quat_t q_inverse(quat_t a) {                        /* :474-477 */
+    const float n = 1.0f / (a.i * a.i + a.j * a.j + a.k * a.k + a.e * a.e);
+    quat_t c = {-a.i, -a.j, -a.k, a.e};
+    return q_scale(c, n);
+}
+static quat_t q_slerp_from_identity(quat_t b, float l) {   /* SLerp(Identity, b)[l], :1312-1337 */
+    const quat_t a = q_identity();
+    float comega = a.e * b.e + a.i * b.i + a.j * b.j + a.k * b.k;
+    const int flip = comega < 0.0f;
+    if (flip) comega = -comega;
+    const float omega = f_acos(comega);
+    if (omega > (float)MMDX_EPS_D) {
+        const float rs = 1.0f / f_sin(omega);
+        const float p = f_sin((1.0f - l) * omega) * rs;
+        l = f_sin(l * omega) * rs;
+        if (flip) l = -l;
+        return q_add(q_scale(a, p), q_scale(b, l));
+    }
+    return a;
+}
+static void q_to_matrix(quat_t q, float *m) {              /* :540-563 */
+    const float ii = q.i * q.i, jj = q.j * q.j, kk = q.k * q.k, ij = q.i * q.j, jk = q.j * q.k, ki = q.i * q.k;
+    const float ie = q.i * q.e, je = q.j * q.e, ke = q.k * q.e;
+    m[0] = 1.0f - 2.0f * (jj + kk); m[1] = 2.0f * (ij + ke); m[2] = 2.0f * (ki - je); m[3] = 0.0f;
+    m[4] = 2.0f * (ij - ke); m[5] = 1.0f - 2.0f * (kk + ii); m[6] = 2.0f * (jk + ie); m[7] = 0.0f;
+    m[8] = 2.0f * (ki + je); m[9] = 2.0f * (jk - ie); m[10] = 1.0f - 2.0f * (ii + jj); m[11] = 0.0f;
+    m[12] = m[13] = m[14] = 0.0f; m[15] = 1.0f;
+}
+static void v3_normalize(float *v) {                       /* :390-400 */
+    const float n = 1.0f / f_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] = v[0] * n; v[1] = v[1] * n; v[2] = v[2] * n;
+}
+static float v3_dot(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static quat_t axis_to_quat(const float *axis, float angle) {   /* :1047-1058 */
+    const float norm = f_sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+    if (norm < (float)MMDX_EPS_D) return q_identity();
+    angle *= 0.5f;
+    const float s = f_sin(angle) / norm;
+    quat_t q = {s * axis[0], s * axis[1], s * axis[2], f_cos(angle)};
+    return q;
+}
+
+/* Quaternion <-> Euler for the three orders the IK uses, :1059-1071 / :1110-1135 and :1137-1223 */
+static void quat_to_euler(int order, quat_t q, float *r) {
+    const float ii = q.i * q.i, jj = q.j * q.j, kk = q.k * q.k;
+    const float ei = q.e * q.i, ej = q.e * q.j, ek = q.e * q.k;
+    const float ij = q.i * q.j, ik = q.i * q.k, jk = q.j * q.k;
+    if (order == ORDER_ZXY) {
+        r[0] = f_asin(2.0f * (ei + jk));
+        r[1] = f_atan2(2.0f * (ej - ik), 1 - 2.0f * (ii + jj));
+        r[2] = f_atan2(2.0f * (ek - ij), 1 - 2.0f * (ii + kk));
+    } else if (order == ORDER_XYZ) {
+        r[0] = f_atan2(2.0f * (ei - jk), 1 - 2.0f * (ii + jj));
+        r[1] = f_asin(2.0f * (ej + ik));
+        r[2] = f_atan2(2.0f * (ek - ij), 1 - 2.0f * (jj + kk));
+    } else {
+        r[0] = f_atan2(2.0f * (ei - jk), 1 - 2.0f * (ii + kk));
+        r[1] = f_atan2(2.0f * (ej - ik), 1 - 2.0f * (jj + kk));
+        r[2] = f_asin(2.0f * (ek + ij));
+    }
+}
+static quat_t euler_to_quat(int order, const float *r) {
+    const float cx = f_cos(r[0] * 0.5f), sx = f_sin(r[0] * 0.5f);
+    const float cy = f_cos(r[1] * 0.5f), sy = f_sin(r[1] * 0.5f);
+    const float cz = f_cos(r[2] * 0.5f), sz = f_sin(r[2] * 0.5f);
+    quat_t q;
+    if (order == ORDER_ZXY) {
+        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz - cx * sy * sz;
+        q.j = cx * sy * cz + sx * cy * sz; q.k = cx * cy * sz + sx * sy * cz;
+    } else if (order == ORDER_XYZ) {
+        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz + cx * sy * sz;
+        q.j = cx * sy * cz - sx * cy * sz; q.k = sx * sy * cz + cx * cy * sz;
+    } else {
+        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz + cx * sy * sz;
+        q.j = cx * sy * cz + sx * cy * sz; q.k = cx * cy * sz - sx * sy * cz;
+    }
+    return q;
+}
+static void limit_euler(float *e, const float *lo, const float *hi, int ikt) {   /* poser_impl.inl:178-194 */
+    for (int i = 0; i < 3; ++i) {
+        if (e[i] < lo[i]) {
+            const float tf = 2 * lo[i] - e[i];
+            e[i] = (tf <= hi[i] && ikt) ? tf : lo[i];
+        }
+        if (e[i] > hi[i]) {
+            const float tf = 2 * hi[i] - e[i];
+            e[i] = (tf >= lo[i] && ikt) ? tf : hi[i];
+        }
+    }
+}
+
+static int has_parent(const solve_ctx *c, uint32_t b) { return c->parent[b] >= 0 && (uint64_t)c->parent[b] < c->nb; }
+
+static void place(const solve_ctx *c, uint32_t b) {        /* rotation -> local matrix, then the parent product */
+    bone_state_t *s = &c->st[b];
+    q_to_matrix(s->total_rot, s->local);
+    for (int k = 0; k < 3; ++k) {
+        const float off = has_parent(c, b) ? c->rest[3 * (size_t)b + k] - c->rest[3 * (size_t)c->parent[b] + k]
+                                           : c->rest[3 * (size_t)b + k];
+        s->local[12 + k] = s->total_tr[k] + off;
+    }
+    if (has_parent(c, b)) mat_mul(s->local, c->st[c->parent[b]].local, s->local);
+}
+
+static void update_bone(const solve_ctx *c, uint32_t b, int solve_ik);
+
+static void solve_ik_chain(const solve_ctx *c, uint32_t b) {
+    bone_state_t *st = c->st;
+    const uint32_t l0 = c->ik_link_off[b], n = c->ik_link_off[b + 1] - l0;
+    const uint32_t target = (uint32_t)c->ik_target[b];
+    uint32_t limit = c->ik_loop[b] < 0 || c->ik_loop[b] > 256 ? 256u : (uint32_t)c->ik_loop[b];   /* min(size_t(loop), 256) */
+    float ik_pos[3], tgt_pos[3], err[3];
+    for (uint32_t i = 0; i < n; ++i) st[c->ik_link_bone[l0 + i]].ik_rot = q_identity();
+    memcpy(ik_pos, st[b].local + 12, 12);
+    for (uint32_t i = 0; i < n; ++i) update_bone(c, (uint32_t)c->ik_link_bone[l0 + n - i - 1], 1);
+    update_bone(c, target, 1);
+    memcpy(tgt_pos, st[target].local + 12, 12);
+    for (int k = 0; k < 3; ++k) err[k] = ik_pos[k] - tgt_pos[k];
+    if (v3_dot(err, err) < (float)MMDX_EPS_D) return;
+    const uint32_t ikt = limit / 2;
+    for (uint32_t i = 0; i < limit; ++i) {
+        for (uint32_t j = 0; j < n; ++j) {
+            /* per-link constants of the Poser ctor (:63-90) */
+            const int limited = c->ik_link_limited[l0 + j] != 0;
+            float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            int order = ORDER_YZX, fix = FIX_NONE;
+            if (limited) {
+                const float *a = c->ik_link_lo + 3 * (size_t)(l0 + j), *z = c->ik_link_hi + 3 * (size_t)(l0 + j);
+                for (int k = 0; k < 3; ++k) { lo[k] = z[k] < a[k] ? z[k] : a[k]; hi[k] = a[k] < z[k] ? z[k] : a[k]; }
+                const double half_pi = 3.141592653589793238462643383279502884 * 0.5f;
+                if (lo[0] > -half_pi && hi[0] < half_pi) order = ORDER_ZXY;
+                else if (lo[1] > -half_pi && hi[1] < half_pi) order = ORDER_XYZ;
+                const int zx = fabsf(lo[0]) < 1e-7f && fabsf(hi[0]) < 1e-7f;
+                const int zy = fabsf(lo[1]) < 1e-7f && fabsf(hi[1]) < 1e-7f;
+                const int zz = fabsf(lo[2]) < 1e-7f && fabsf(hi[2]) < 1e-7f;
+                if (zx && zy && zz) fix = FIX_ALL;
+                else if (zy && zz) fix = FIX_X;
+                else if (zx && zz) fix = FIX_Y;
+                else if (zx && zy) fix = FIX_Z;
+            }
+            if (fix == FIX_ALL) continue;
+            const uint32_t lb = (uint32_t)c->ik_link_bone[l0 + j];
+            bone_state_t *li = &st[lb];
+            float tdir[3], idir[3], axis[3];
+            for (int k = 0; k < 3; ++k) { tdir[k] = li->local[12 + k] - tgt_pos[k]; idir[k] = li->local[12 + k] - ik_pos[k]; }
+            v3_normalize(tdir);
+            v3_normalize(idir);
+            axis[0] = tdir[1] * idir[2] - tdir[2] * idir[1];
+            axis[1] = tdir[2] * idir[0] - tdir[0] * idir[2];
+            axis[2] = tdir[0] * idir[1] - tdir[1] * idir[0];
+            for (int k = 0; k < 3; ++k) if (fabsf(axis[k]) < 1e-7f) axis[k] = 1e-7f;
+            float loc[16];
+            if (has_parent(c, lb)) memcpy(loc, st[c->parent[lb]].local, 64); else mat_identity(loc);
+            if (limited && fix != FIX_NONE && i < ikt) {
+                const float d = v3_dot(axis, loc + 4 * (fix - FIX_X));
+                axis[0] = axis[1] = axis[2] = 0.0f;
+                axis[fix - FIX_X] = d >= 0.0f ? 1.0f : -1.0f;
+            } else {                                           /* rotate(axis, loc.Transpose()) then Normalize */
+                float r[3];
+                for (int x = 0; x < 3; ++x) r[x] = axis[0] * loc[4 * x + 0] + axis[1] * loc[4 * x + 1] + axis[2] * loc[4 * x + 2];
+                memcpy(axis, r, 12);
+                v3_normalize(axis);
+            }
+            float dot = v3_dot(tdir, idir);
+            dot = dot < -1.0f ? -1.0f : dot;                   /* clamp = min(max(x, lo), hi), math.inl:45-47 */
+            dot = 1.0f < dot ? 1.0f : dot;
+            const float ac = f_acos(dot), cap = c->ik_angle[b] * (j + 1);
+            const float angle = cap < ac ? cap : ac;
+            li->ik_rot = q_mul(axis_to_quat(axis, angle), li->ik_rot);
+            if (limited) {
+                quat_t lr = q_mul(li->ik_rot, li->pre_ik_rot);
+                float e[3];
+                quat_to_euler(order, lr, e);
+                limit_euler(e, lo, hi, i < ikt);
+                lr = euler_to_quat(order, e);
+                li->ik_rot = q_mul(lr, q_inverse(li->pre_ik_rot));
+            }
+            for (uint32_t k = 0; k <= j; ++k) {
+                const uint32_t bb = (uint32_t)c->ik_link_bone[l0 + j - k];
+                st[bb].total_rot = q_mul(st[bb].ik_rot, st[bb].pre_ik_rot);
+                place(c, bb);
+            }
+            update_bone(c, target, 1);
+            memcpy(tgt_pos, st[target].local + 12, 12);
+        }
+        for (int k = 0; k < 3; ++k) err[k] = ik_pos[k] - tgt_pos[k];
+        if (v3_dot(err, err) < (float)MMDX_EPS_D) return;
+    }
+}
+
+static void update_bone(const solve_ctx *c, uint32_t b, int solve_ik) {
+    bone_state_t *s = &c->st[b];
+    const float *t = c->poses + 8 * (size_t)b;
+    const quat_t rot = {t[4], t[5], t[6], t[7]};
+    const uint16_t f = c->flags ? c->flags[b] : 0;
+    s->total_rot = q_mul(q_identity(), rot);
+    for (int k = 0; k < 3; ++k) s->total_tr[k] = 0.0f + t[k];
+    if ((f & 0x0300) && c->append_parent[b] >= 0 && (uint64_t)c->append_parent[b] < c->nb) {
+        const bone_state_t *ap = &c->st[c->append_parent[b]];
+        if (f & 0x0100) s->total_rot = q_mul(s->total_rot, q_slerp_from_identity(ap->total_rot, c->append_ratio[b]));
+        if (f & 0x0200) for (int k = 0; k < 3; ++k) s->total_tr[k] = s->total_tr[k] + c->append_ratio[b] * ap->total_tr[k];
+    }
+    if (c->is_ik_link[b]) {
+        s->pre_ik_rot = s->total_rot;
+        s->total_rot = q_mul(s->ik_rot, s->total_rot);
+    }
+    place(c, b);
+    if (solve_ik && (f & 0x0020)) solve_ik_chain(c, b);
+}
+
+/* Everything as flat arrays (NULL allowed where no bone uses it): append_parent / append_ratio [NB];
+ * ik_target [NB], ik_loop [NB], ik_angle [NB], ik_link_off [NB+1], ik_link_bone / ik_link_limited [L],
+ * ik_link_lo / ik_link_hi [L][3].  scratch = NB * (sizeof(bone_state_t) + 5) bytes.  Returns -1 when an IK
+ * link or target is itself an IK bone (recursive solves are not restated) or an index is out of range. */
+int mmdx_oracle_bone_solve_full(uint32_t nb, const float *rest, const int64_t *parent, const int32_t *level,
+                                const uint16_t *flags, const int64_t *append_parent, const float *append_ratio,
+                                const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
+                                const uint32_t *ik_link_off, const int64_t *ik_link_bone,
+                                const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi,
+                                const float *poses, float *out, void *scratch) {
+    bone_state_t *st = (bone_state_t *)scratch;
+    uint32_t *order = (uint32_t *)(st + nb);
+    uint8_t *is_link = (uint8_t *)(order + nb);
+    uint32_t n = 0, n_pre = 0;
+    memset(is_link, 0, nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (!(flags && (flags[b] & 0x0020))) continue;
+        if (ik_target[b] < 0 || (uint64_t)ik_target[b] >= nb || (flags[ik_target[b]] & 0x0020)) return -1;
+        for (uint32_t l = ik_link_off[b]; l < ik_link_off[b + 1]; ++l) {
+            if (ik_link_bone[l] < 0 || (uint64_t)ik_link_bone[l] >= nb || (flags[ik_link_bone[l]] & 0x0020)) return -1;
+            is_link[ik_link_bone[l]] = 1;
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t first = n;
+        for (uint32_t b = 0; b < nb; ++b)
+            if ((int)((flags ? flags[b] : 0) >> 12 & 1) == pass) order[n++] = b;
+        for (uint32_t i = first + 1; i < n; ++i) {
+            const uint32_t b = order[i];
+            const uint64_t lb = (uint64_t)(int64_t)(level ? level[b] : 0);
+            uint32_t j = i;
+            while (j > first) {
+                const uint32_t cb = order[j - 1];
+                const uint64_t lc = (uint64_t)(int64_t)(level ? level[cb] : 0);
+                if (lc < lb || (lc == lb && cb < b)) break;
+                order[j] = cb;
+                --j;
+            }
+            order[j] = b;
+        }
+        if (pass == 0) n_pre = n;
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        st[b].total_rot = st[b].ik_rot = st[b].pre_ik_rot = q_identity();
+        st[b].total_tr[0] = st[b].total_tr[1] = st[b].total_tr[2] = 0.0f;
+        mat_identity(st[b].local);
+    }
+    const solve_ctx c = {nb, rest, parent, append_parent, ik_target, ik_link_bone, flags, append_ratio, ik_angle,
+                         ik_link_lo, ik_link_hi, ik_loop, ik_link_off, ik_link_limited, is_link, poses, st};
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t s0 = pass ? n_pre : 0, s1 = pass ? nb : n_pre;
+        for (uint32_t s = s0; s < s1; ++s) update_bone(&c, order[s], 1);
+        for (uint32_t s = s0; s < s1; ++s) {                /* UpdateBoneSkinningMatrix of this list */
+            const uint32_t b = order[s];
+            float g[16];
+            mat_identity(g);
+            g[12] = -rest[3 * (size_t)b]; g[13] = -rest[3 * (size_t)b + 1]; g[14] = -rest[3 * (size_t)b + 2];
+            mat_mul(g, st[b].local, out + 16 * (size_t)b);
+        }
+    }
+    return 0;
+}
+
 /* ---- cpu_baseline timing helpers (kind "port"; seconds, single thread) ---------------------- */
 static double now_s(void) {
     struct timespec ts;

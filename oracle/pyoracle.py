@@ -143,6 +143,28 @@ class Oracle:
             raise ValueError("oracle bone solve: IK / append bones are not restated")
         return out
 
+    def bone_solve_full(self, rest, parent, poses, level=None, flags=None, append_parent=None, append_ratio=None,
+                        ik=None):
+        """The whole bone solve incl. append bones and CCD-IK: poses f32 [NB,8] -> palette f32 [NB,16]."""
+        rest = _c(rest, np.float32).reshape(-1, 3)
+        nb = rest.shape[0]
+        arrs = [rest, _c(parent, np.int64).reshape(nb),
+                _c(level, np.int32).reshape(nb) if level is not None else None,
+                _c(flags, np.uint16).reshape(nb) if flags is not None else np.zeros(nb, np.uint16),
+                _c(append_parent, np.int64).reshape(nb) if append_parent is not None else None,
+                _c(append_ratio, np.float32).reshape(nb) if append_ratio is not None else None] + ik_arrays(ik)
+        types = [C.c_float, C.c_int64, C.c_int32, C.c_uint16, C.c_int64, C.c_float] + IK_TYPES
+        poses = _c(poses, np.float32).reshape(nb, 8)
+        out = np.zeros((nb, 16), np.float32)
+        scratch = np.zeros(nb * 140 + 64, np.uint8)
+        self.lib.mmdx_oracle_bone_solve_full.restype = C.c_int
+        rc = self.lib.mmdx_oracle_bone_solve_full(
+            C.c_uint32(nb), *[_p(a, t) if a is not None else None for a, t in zip(arrs, types)],
+            _p(poses, C.c_float), _p(out, C.c_float), scratch.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise ValueError("oracle bone solve: nested IK or an index out of range")
+        return out
+
     def time_crowd(self, model, rates, palettes, normalize=True):
         """Seconds for one crowd step (shared morph pass + one skinning pass per palette)."""
         t, ids, w = self.normalize(model) if normalize else (
@@ -161,6 +183,18 @@ class Oracle:
             _p(_c(model.morph_value, np.float32), C.c_float), _p(_c(rates, np.float32), C.c_float),
             C.c_uint32(pal.shape[0]), _p(pal, C.c_float), _p(vimg, C.c_float), _p(op, C.c_float),
             _p(on, C.c_float)))
+
+
+IK_TYPES = [C.c_int64, C.c_int32, C.c_float, C.c_uint32, C.c_int64, C.c_uint8, C.c_float, C.c_float]
+
+
+def ik_arrays(ik):
+    """The eight flat IK arrays in ABI order (None each when the rig has no IK)."""
+    if ik is None:
+        return [None] * 8
+    return [_c(ik["target"], np.int64), _c(ik["loop"], np.int32), _c(ik["angle"], np.float32),
+            _c(ik["link_off"], np.uint32), _c(ik["link_bone"], np.int64), _c(ik["link_limited"], np.uint8),
+            _c(ik["link_lo"], np.float32), _c(ik["link_hi"], np.float32)]
 
 
 def reference_available() -> bool:
@@ -239,8 +273,10 @@ class Reference:
             _p(k[12], C.c_float), C.c_int(1 if normalize else 0)))
 
     @classmethod
-    def skeleton(cls, rest, parent, level=None, flags=None, append_parent=None, append_ratio=None) -> "Reference":
-        """Bones-only libmmd model + Poser, for the bone solve (set_bone_pose / pose / get_palette)."""
+    def skeleton(cls, rest, parent, level=None, flags=None, append_parent=None, append_ratio=None, ik=None) -> "Reference":
+        """Bones-only libmmd model + Poser, for the bone solve (set_bone_pose / pose / get_palette).
+        ik = dict(target i64[NB], loop i32[NB], angle f32[NB], link_off u32[NB+1], link_bone i64[L],
+        link_limited u8[L], link_lo f32[L,3], link_hi f32[L,3]) or None."""
         if not reference_available():
             raise RuntimeError("oracle/_ref/libmmd_ref.so not built (needs /root/reference)")
         self = cls.__new__(cls)
@@ -254,6 +290,8 @@ class Reference:
                 _c(append_parent, np.int64).reshape(nb) if append_parent is not None else None,
                 _c(append_ratio, np.float32).reshape(nb) if append_ratio is not None else None]
         types = [C.c_float, C.c_int64, C.c_int32, C.c_uint16, C.c_int64, C.c_float]
+        keep += ik_arrays(ik)
+        types += IK_TYPES
         h = lib.mmdref_create_skeleton(C.c_uint32(nb), *[_p(a, t) if a is not None else None
                                                          for a, t in zip(keep, types)])
         self.lib, self._keep, self.h = lib, keep, C.c_void_p(h)

@@ -280,10 +280,13 @@ int mmdref_motion_bone_pose(void *h, const char *sjis_name, uint32_t frame, floa
 // A bones-only model (no vertices, no morphs) for the bone solve: Poser ctor ordering
 // (poser_impl.inl:99-109), UpdateBoneTransform / UpdateBoneSkinningMatrix (:142-166, :320-326).
 // flags = PMX bone flag word (0x20 IK, 0x100/0x200 append rotate/translate, 0x1000 post-physics);
-// append_parent / append_ratio may be NULL when no bone appends.
+// append_* may be NULL when no bone appends, ik_* when no bone has IK.
 void *mmdref_create_skeleton(uint32_t nb, const float *bone_pos, const int64_t *bone_parent,
                              const int32_t *level, const uint16_t *flags,
-                             const int64_t *append_parent, const float *append_ratio) {
+                             const int64_t *append_parent, const float *append_ratio,
+                             const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
+                             const uint32_t *ik_link_off, const int64_t *ik_link_bone,
+                             const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi) {
     Ref *r = new Ref;
     mmd::Model &m = r->model;
     m.SetExtraUVNumber(0);
@@ -294,7 +297,21 @@ void *mmdref_create_skeleton(uint32_t nb, const float *bone_pos, const int64_t *
         bone.SetPosition(V3(bone_pos + 3 * b));
         bone.SetParentIndex(bone_parent[b] < 0 ? size_t(-1) : size_t(bone_parent[b]));
         bone.SetTransformLevel(size_t(level ? level[b] : 0));
-        bone.SetHasIK(false);
+        bone.SetHasIK((f & 0x0020) != 0);
+        if (f & 0x0020) {                                  // as PmxReader fills it, pmx_reader_impl.inl:249-263
+            bone.SetIKTargetIndex(size_t(ik_target[b]));
+            bone.SetCCDIterateLimit(size_t(ik_loop[b]));
+            bone.SetCCDAngleLimit(ik_angle[b]);
+            for (uint32_t l = ik_link_off[b]; l < ik_link_off[b + 1]; ++l) {
+                mmd::Model::Bone::IKLink &link = bone.NewIKLink();
+                link.SetLinkIndex(size_t(ik_link_bone[l]));
+                link.SetHasLimit(ik_link_limited[l] != 0);
+                if (ik_link_limited[l]) {
+                    link.SetLoLimit(V3(ik_link_lo + 3 * l));
+                    link.SetHiLimit(V3(ik_link_hi + 3 * l));
+                }
+            }
+        }
         bone.SetAppendRotate((f & 0x0100) != 0);
         bone.SetAppendTranslate((f & 0x0200) != 0);
         if (f & 0x0300) {

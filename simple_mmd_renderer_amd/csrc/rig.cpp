@@ -89,14 +89,16 @@ void build_bone_motion(const std::vector<std::string> &track_names, const std::v
     }
 }
 
-std::string build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out) {
+mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::string &err) {
     out = SkeletonPlan();
     const uint32_t nb = d.n_bones;
-    if (nb && (!d.rest_position || !d.parent)) return "rest_position / parent is NULL";
+    auto bad = [&](mmdx_status st, const std::string &what) { err = what; return st; };
+    if (nb && (!d.rest_position || !d.parent)) return bad(MMDX_ERR_INVALID_ARGUMENT, "rest_position / parent is NULL");
     out.nb = nb;
     std::vector<uint32_t> pre, post;
+    auto flag = [&](uint32_t b) -> uint16_t { return d.flags ? d.flags[b] : uint16_t(0); };
     for (uint32_t b = 0; b < nb; ++b) {
-        const uint16_t f = d.flags ? d.flags[b] : 0;
+        const uint16_t f = flag(b);
         if (f & (MMDX_BONE_HAS_IK | MMDX_BONE_APPEND_ROTATE | MMDX_BONE_APPEND_TRANSLATE)) out.serial = true;
         (f & MMDX_BONE_POST_PHYSICS ? post : pre).push_back(b);
     }
@@ -115,6 +117,8 @@ std::string build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out) {
         const int32_t p = d.parent[b];
         return (p >= 0 && uint32_t(p) < nb) ? int64_t(p) : -1;
     };
+    for (uint32_t b = 0; b < nb; ++b)
+        if (parent_of(b) == int64_t(b)) return bad(MMDX_ERR_INVALID_ARGUMENT, "bone " + std::to_string(b) + " is its own parent");
     out.local_offset.resize(size_t(nb) * 4, 0.0f);
     out.neg_rest.resize(size_t(nb) * 4, 0.0f);
     for (uint32_t b = 0; b < nb; ++b) {
@@ -125,28 +129,102 @@ std::string build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out) {
             out.neg_rest[4 * size_t(b) + k] = -pos[k];
         }
     }
-    // Parent chains.  A parent that comes LATER in the evaluation sequence still holds the identity
-    // its local matrix was reset to (PrePhysicsPosing, poser_impl.inl:371): the chain then starts with
-    // kIdentityParent and that product is carried out like any other.
-    out.chain_off.push_back(0);
-    std::vector<uint32_t> rev;
-    for (uint32_t b = 0; b < nb; ++b) {
-        rev.clear();
-        uint32_t c = b;
-        for (;;) {
-            rev.push_back(c);
-            const int64_t p = parent_of(c);
-            if (p < 0) break;
-            if (uint32_t(p) == c) return "bone " + std::to_string(c) + " is its own parent";
-            if (seq[uint32_t(p)] > seq[c]) { rev.push_back(kIdentityParent); break; }
-            c = uint32_t(p);
+    if (!out.serial) {
+        // Parent chains.  A parent that comes LATER in the evaluation sequence still holds the identity
+        // its local matrix was reset to (PrePhysicsPosing, poser_impl.inl:371): the chain then starts with
+        // kIdentityParent and that product is carried out like any other.
+        out.chain_off.push_back(0);
+        std::vector<uint32_t> rev;
+        for (uint32_t b = 0; b < nb; ++b) {
+            rev.clear();
+            uint32_t c = b;
+            for (;;) {
+                rev.push_back(c);
+                const int64_t p = parent_of(c);
+                if (p < 0) break;
+                if (seq[uint32_t(p)] > seq[c]) { rev.push_back(kIdentityParent); break; }
+                c = uint32_t(p);
+            }
+            if (out.chain.size() + rev.size() > (size_t(1) << 26))
+                return bad(MMDX_ERR_UNSUPPORTED, "parent chains too long for the parallel bone solve");
+            out.max_chain = std::max(out.max_chain, uint32_t(rev.size()));
+            out.chain.insert(out.chain.end(), rev.rbegin(), rev.rend());
+            out.chain_off.push_back(uint32_t(out.chain.size()));
         }
-        if (out.chain.size() + rev.size() > (size_t(1) << 26)) return "parent chains too long for the parallel bone solve";
-        out.max_chain = std::max(out.max_chain, uint32_t(rev.size()));
-        out.chain.insert(out.chain.end(), rev.rbegin(), rev.rend());
-        out.chain_off.push_back(uint32_t(out.chain.size()));
+        return MMDX_OK;
     }
-    return "";
+
+    // ---- serial solver tables (Poser ctor, L/motion/poser_impl.inl:29-97) -----------------------
+    out.bones.resize(nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        BoneRec &r = out.bones[b];
+        r = BoneRec();
+        for (int k = 0; k < 3; ++k) { r.local_offset[k] = out.local_offset[4 * size_t(b) + k]; r.neg_rest[k] = out.neg_rest[4 * size_t(b) + k]; }
+        r.parent = int32_t(parent_of(b));
+        r.append_parent = -1;
+        const uint16_t f = flag(b);
+        if (f & (MMDX_BONE_APPEND_ROTATE | MMDX_BONE_APPEND_TRANSLATE)) {
+            if (!d.append_parent || !d.append_ratio)
+                return bad(MMDX_ERR_INVALID_ARGUMENT, "append bones present but append_parent / append_ratio is NULL");
+            const int32_t ap = d.append_parent[b];
+            if (ap >= 0 && uint32_t(ap) < nb) {            // otherwise has_append_ stays false
+                r.append_parent = ap;
+                r.append_ratio = d.append_ratio[b];
+                if (f & MMDX_BONE_APPEND_ROTATE) r.bits |= kBoneAppendRot;
+                if (f & MMDX_BONE_APPEND_TRANSLATE) r.bits |= kBoneAppendTr;
+                ++out.n_append;
+            }
+        }
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (!(flag(b) & MMDX_BONE_HAS_IK)) continue;
+        if (!d.ik_target || !d.ik_loop_count || !d.ik_angle_limit || !d.ik_link_offset)
+            return bad(MMDX_ERR_INVALID_ARGUMENT, "IK bones present but an ik_* array is NULL");
+        const uint32_t l0 = d.ik_link_offset[b], l1 = d.ik_link_offset[b + 1];
+        if (l1 < l0 || (l1 > l0 && (!d.ik_link_bone || !d.ik_link_limited)))
+            return bad(MMDX_ERR_INVALID_ARGUMENT, "ik_link_offset is not ascending or the link arrays are NULL");
+        const int32_t tgt = d.ik_target[b];
+        if (tgt < 0 || uint32_t(tgt) >= nb) return bad(MMDX_ERR_BAD_INDEX, "IK target of bone " + std::to_string(b) + " is out of range");
+        if (flag(uint32_t(tgt)) & MMDX_BONE_HAS_IK) return bad(MMDX_ERR_UNSUPPORTED, "IK target of bone " + std::to_string(b) + " is itself an IK bone");
+        IkRec ik = IkRec();
+        ik.target = uint32_t(tgt);
+        const int32_t loop = d.ik_loop_count[b];
+        ik.loop = (loop < 0 || loop > 256) ? 256u : uint32_t(loop);
+        ik.angle_limit = d.ik_angle_limit[b];
+        ik.link0 = uint32_t(out.links.size());
+        ik.nlinks = l1 - l0;
+        for (uint32_t l = l0; l < l1; ++l) {
+            const int32_t lb = d.ik_link_bone[l];
+            if (lb < 0 || uint32_t(lb) >= nb) return bad(MMDX_ERR_BAD_INDEX, "IK link of bone " + std::to_string(b) + " is out of range");
+            if (flag(uint32_t(lb)) & MMDX_BONE_HAS_IK) return bad(MMDX_ERR_UNSUPPORTED, "IK link of bone " + std::to_string(b) + " is itself an IK bone");
+            LinkRec lr = LinkRec();
+            lr.bone = uint32_t(lb);
+            lr.limited = d.ik_link_limited[l] ? 1u : 0u;
+            lr.order = kOrderYZX;
+            lr.fix = kFixNone;
+            if (lr.limited) {
+                if (!d.ik_link_lo || !d.ik_link_hi) return bad(MMDX_ERR_INVALID_ARGUMENT, "limited IK links present but ik_link_lo / ik_link_hi is NULL");
+                const float *a = d.ik_link_lo + 3 * size_t(l), *z = d.ik_link_hi + 3 * size_t(l);
+                for (int k = 0; k < 3; ++k) { lr.lo[k] = std::min(a[k], z[k]); lr.hi[k] = std::max(a[k], z[k]); }
+                const double half_pi = 3.141592653589793238462643383279502884 * 0.5f;
+                if (lr.lo[0] > -half_pi && lr.hi[0] < half_pi) lr.order = kOrderZXY;
+                else if (lr.lo[1] > -half_pi && lr.hi[1] < half_pi) lr.order = kOrderXYZ;
+                auto zero = [&](int k) { return std::fabs(lr.lo[k]) < 1e-7f && std::fabs(lr.hi[k]) < 1e-7f; };
+                if (zero(0) && zero(1) && zero(2)) lr.fix = kFixAll;
+                else if (zero(1) && zero(2)) lr.fix = kFixX;
+                else if (zero(0) && zero(2)) lr.fix = kFixY;
+                else if (zero(0) && zero(1)) lr.fix = kFixZ;
+            }
+            out.links.push_back(lr);
+            out.bones[uint32_t(lb)].bits |= kBoneIsIkLink;
+        }
+        out.bones[b].bits |= kBoneHasIk;
+        out.bones[b].ik = uint32_t(out.iks.size());
+        out.iks.push_back(ik);
+    }
+    out.n_ik = uint32_t(out.iks.size());
+    out.n_links = uint32_t(out.links.size());
+    return MMDX_OK;
 }
 
 }  // namespace mmdx

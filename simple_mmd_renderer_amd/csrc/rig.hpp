@@ -45,18 +45,48 @@ struct BoneTrackParams {
 };
 
 // ---- skeleton: local poses -> skinning palette --------------------------------------------------
+enum : uint32_t { kBoneAppendRot = 1u, kBoneAppendTr = 2u, kBoneIsIkLink = 4u, kBoneHasIk = 8u };
+enum : uint32_t { kFixNone = 0, kFixX = 1, kFixY = 2, kFixZ = 3, kFixAll = 4 };
+enum : uint32_t { kOrderZXY = 0, kOrderXYZ = 1, kOrderYZX = 2 };
+
+struct BoneRec {                                // serial solver: everything static about one bone (48 B)
+    float local_offset[3];
+    int32_t parent;                             // -1 = none
+    float neg_rest[3];
+    int32_t append_parent;                      // valid iff bits has kBoneAppendRot/Tr
+    float append_ratio;
+    uint32_t bits;
+    uint32_t ik;                                // index into iks when kBoneHasIk
+    uint32_t pad;
+};
+struct IkRec {
+    uint32_t target, loop, link0, nlinks;       // loop already clamped to <= 256
+    float angle_limit;
+    uint32_t pad[3];
+};
+struct LinkRec {                                // the per-link constants the Poser ctor derives (48 B)
+    uint32_t bone, limited, order, fix;
+    float lo[4], hi[4];                         // min / max per component, [3] unused
+};
+
 struct SkeletonPlan {
     uint32_t nb = 0, n_pre = 0, n_post = 0, max_chain = 0;
+    uint32_t n_ik = 0, n_links = 0, n_append = 0;
     bool serial = false;                        // IK or append bones present: not a pure parent-chain FK
     std::vector<uint32_t> order;                // evaluation sequence: pre-physics sorted, then post-physics sorted
+    // parallel FK
     std::vector<float> local_offset;            // [nb][4] rest position relative to the parent (or absolute)
     std::vector<float> neg_rest;                // [nb][4] -rest position: translation row of the global offset
     std::vector<uint32_t> chain_off;            // [nb+1]
     std::vector<uint32_t> chain;                // per bone: kIdentityParent? then ancestors root-first, the bone last
+    // serial solver
+    std::vector<BoneRec> bones;
+    std::vector<IkRec> iks;
+    std::vector<LinkRec> links;
 };
 
-// Throws nothing; returns an error text ("" = ok).
-std::string build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out);
+// status: MMDX_OK, or the error code with its text in `err`.
+mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::string &err);
 
 struct SkeletonParams {
     const float *poses;                         // [ni][nb][8]
@@ -64,6 +94,19 @@ struct SkeletonParams {
     const float *local_offset, *neg_rest;       // float4 per bone
     const uint32_t *chain_off, *chain;
     uint32_t nb, ni;
+};
+
+constexpr uint32_t kSerialStateFloats = 4 + 4 + 4 + 3 + 16;   // total_rot, ik_rot, pre_ik_rot, total_tr, local
+
+struct SerialParams {
+    const float *poses;                         // [ni][nb][8]
+    float *out;                                 // [ni][nb][16]
+    float *state;                               // [nb][kSerialStateFloats][ni] scratch, instance fastest
+    const uint32_t *order;
+    const BoneRec *bones;
+    const IkRec *iks;
+    const LinkRec *links;
+    uint32_t nb, ni, n_pre;
 };
 
 }  // namespace mmdx

@@ -60,6 +60,11 @@ struct mmdx_skeleton_s {
     SkeletonPlan plan;
     int device = -1;
     Buf local_offset, neg_rest, chain_off, chain, poses_in, out;
+    Buf order, bones, iks, links, state;                  // serial solver
+    void release_all() {
+        for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &state})
+            b->release();
+    }
 };
 
 extern "C" {
@@ -156,11 +161,8 @@ mmdx_status mmdx_skeleton_create(const mmdx_skeleton_desc *desc, mmdx_skeleton_t
     *out = nullptr;
     try {
         std::unique_ptr<mmdx_skeleton_s> s(new mmdx_skeleton_s);
-        const std::string err = build_skeleton(*desc, s->plan);
-        if (!err.empty()) return fail(MMDX_ERR_INVALID_ARGUMENT, "skeleton: " + err);
-        if (s->plan.serial)
-            return fail(MMDX_ERR_UNSUPPORTED,
-                        "skeleton: IK / append bones need the reference's serial solve; not available on the device");
+        std::string err;
+        if (mmdx_status st = build_skeleton(*desc, s->plan, err)) return fail(st, "skeleton: " + err);
         *out = s.release();
     } catch (const std::bad_alloc &) {
         return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -175,6 +177,10 @@ mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t s, mmdx_skeleton_info *info) 
     info->n_pre_physics = s->plan.n_pre;
     info->n_post_physics = s->plan.n_post;
     info->max_chain = s->plan.max_chain;
+    info->solver = s->plan.serial ? MMDX_SOLVER_SERIAL : MMDX_SOLVER_PARALLEL_FK;
+    info->n_ik_bones = s->plan.n_ik;
+    info->n_ik_links = s->plan.n_links;
+    info->n_append_bones = s->plan.n_append;
     info->reserved0 = 0;
     return MMDX_OK;
 }
@@ -188,19 +194,21 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
     if (mmdx_status r = resolve_stream(model, &device, &st)) return r;
     const SkeletonPlan &pl = s->plan;
     if (s->device != device) {
-        for (Buf *b : {&s->local_offset, &s->neg_rest, &s->chain_off, &s->chain, &s->poses_in, &s->out}) b->release();
-        HIP_TRY(s->local_offset.upload(pl.local_offset));
-        HIP_TRY(s->neg_rest.upload(pl.neg_rest));
-        HIP_TRY(s->chain_off.upload(pl.chain_off));
-        HIP_TRY(s->chain.upload(pl.chain));
+        s->release_all();
+        if (pl.serial) {
+            HIP_TRY(s->order.upload(pl.order));
+            HIP_TRY(s->bones.upload(pl.bones));
+            HIP_TRY(s->iks.upload(pl.iks));
+            HIP_TRY(s->links.upload(pl.links));
+        } else {
+            HIP_TRY(s->local_offset.upload(pl.local_offset));
+            HIP_TRY(s->neg_rest.upload(pl.neg_rest));
+            HIP_TRY(s->chain_off.upload(pl.chain_off));
+            HIP_TRY(s->chain.upload(pl.chain));
+        }
         s->device = device;
     }
-    SkeletonParams p;
-    p.local_offset = static_cast<const float *>(s->local_offset.ptr);
-    p.neg_rest = static_cast<const float *>(s->neg_rest.ptr);
-    p.chain_off = static_cast<const uint32_t *>(s->chain_off.ptr);
-    p.chain = static_cast<const uint32_t *>(s->chain.ptr);
-    p.nb = pl.nb; p.ni = n_instances;
+    struct { const float *poses; float *out; } p;
     const size_t in_bytes = size_t(n_instances) * pl.nb * MMDX_POSE_FLOATS * sizeof(float);
     const size_t out_bytes = size_t(n_instances) * pl.nb * 16 * sizeof(float);
     if (flags & MMDX_POSES_ON_DEVICE) {
@@ -216,7 +224,27 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
         HIP_TRY(s->out.ensure(out_bytes));
         p.out = static_cast<float *>(s->out.ptr);
     }
-    HIP_TRY(launch_skeleton_fk(p, st));
+    if (pl.serial) {
+        HIP_TRY(s->state.ensure(size_t(n_instances) * pl.nb * kSerialStateFloats * sizeof(float)));
+        SerialParams sp;
+        sp.poses = p.poses; sp.out = p.out;
+        sp.state = static_cast<float *>(s->state.ptr);
+        sp.order = static_cast<const uint32_t *>(s->order.ptr);
+        sp.bones = static_cast<const BoneRec *>(s->bones.ptr);
+        sp.iks = static_cast<const IkRec *>(s->iks.ptr);
+        sp.links = static_cast<const LinkRec *>(s->links.ptr);
+        sp.nb = pl.nb; sp.ni = n_instances; sp.n_pre = pl.n_pre;
+        HIP_TRY(launch_skeleton_serial(sp, st));
+    } else {
+        SkeletonParams fp;
+        fp.poses = p.poses; fp.out = p.out;
+        fp.local_offset = static_cast<const float *>(s->local_offset.ptr);
+        fp.neg_rest = static_cast<const float *>(s->neg_rest.ptr);
+        fp.chain_off = static_cast<const uint32_t *>(s->chain_off.ptr);
+        fp.chain = static_cast<const uint32_t *>(s->chain.ptr);
+        fp.nb = pl.nb; fp.ni = n_instances;
+        HIP_TRY(launch_skeleton_fk(fp, st));
+    }
     if (!(flags & MMDX_OUT_ON_DEVICE)) {
         if (out_bytes) HIP_TRY(hipMemcpyAsync(out_palettes, p.out, out_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -229,7 +257,7 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
 void mmdx_skeleton_destroy(mmdx_skeleton_t s) {
     if (!s) return;
     if (s->device >= 0) (void)hipSetDevice(s->device);
-    for (Buf *b : {&s->local_offset, &s->neg_rest, &s->chain_off, &s->chain, &s->poses_in, &s->out}) b->release();
+    s->release_all();
     delete s;
 }
 

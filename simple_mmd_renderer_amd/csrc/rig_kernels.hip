@@ -165,6 +165,310 @@ __global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const Skeleton
     for (int y = 0; y < 4; ++y) out[y] = make_float4(S.m[y][0], S.m[y][1], S.m[y][2], S.m[y][3]);
 }
 
+// ---- serial solver: append (inherit) bones + CCD-IK ------------------------------------------------
+// One thread per instance walks the reference's evaluation sequence (Poser::UpdateBoneTransform,
+// L/motion/poser_impl.inl:142-310) with the per-bone state in HBM scratch laid out [bone][field][instance]
+// (lanes = consecutive instances, so every state access of a wave is one coalesced line).  Bones, IK
+// chains and links are the same for all lanes: those records come through scalar loads.  The float
+// operation order is the reference's; sqrt/sin/cos/asin/acos/atan2 go through double and back like
+// L/util/math.inl:27-45.
+struct Quat {
+    float i, j, k, e;
+};
+enum : uint32_t { kStTotalRot = 0, kStIkRot = 4, kStPreIkRot = 8, kStTotalTr = 12, kStLocal = 15 };
+
+struct State {
+    float *base;      // already offset to this lane's instance
+    size_t ni;
+    __device__ __forceinline__ float &at(uint32_t bone, uint32_t f) const {
+        return base[(size_t(bone) * kSerialStateFloats + f) * ni];
+    }
+    __device__ __forceinline__ Quat quat(uint32_t bone, uint32_t f) const {
+        return {at(bone, f), at(bone, f + 1), at(bone, f + 2), at(bone, f + 3)};
+    }
+    __device__ __forceinline__ void set_quat(uint32_t bone, uint32_t f, const Quat q) const {
+        at(bone, f) = q.i; at(bone, f + 1) = q.j; at(bone, f + 2) = q.k; at(bone, f + 3) = q.e;
+    }
+    __device__ __forceinline__ Mat4 local(uint32_t bone) const {
+        Mat4 m;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m.m[k / 4][k % 4] = at(bone, kStLocal + k);
+        return m;
+    }
+    __device__ __forceinline__ void set_local(uint32_t bone, const Mat4 &m) const {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) at(bone, kStLocal + k) = m.m[k / 4][k % 4];
+    }
+};
+
+__device__ __forceinline__ float d_sqrt(float x) { return float(sqrt(double(x))); }
+__device__ __forceinline__ float d_sin(float x) { return float(sin(double(x))); }
+__device__ __forceinline__ float d_cos(float x) { return float(cos(double(x))); }
+__device__ __forceinline__ float d_asin(float x) { return float(asin(double(x))); }
+__device__ __forceinline__ float d_acos(float x) { return float(acos(double(x))); }
+__device__ __forceinline__ float d_atan2(float y, float x) { return float(atan2(double(y), double(x))); }
+
+__device__ __forceinline__ Quat q_identity() { return {0.f, 0.f, 0.f, 1.f}; }
+__device__ __forceinline__ Quat q_mul(const Quat a, const Quat q) {   // L/util/math_impl.inl:510-517
+    Quat r;
+    r.i = (a.e * q.i + a.i * q.e + a.j * q.k) - a.k * q.j;
+    r.j = (a.e * q.j + a.j * q.e + a.k * q.i) - a.i * q.k;
+    r.k = (a.e * q.k + a.i * q.j + a.k * q.e) - a.j * q.i;
+    r.e = a.e * q.e - (a.i * q.i + a.j * q.j + a.k * q.k);
+    return r;
+}
+__device__ __forceinline__ Quat q_scale(const Quat a, float s) { return {a.i * s, a.j * s, a.k * s, a.e * s}; }
+__device__ __forceinline__ Quat q_inverse(const Quat a) {             // :474-477
+    const float n = 1.0f / (a.i * a.i + a.j * a.j + a.k * a.k + a.e * a.e);
+    return q_scale({-a.i, -a.j, -a.k, a.e}, n);
+}
+__device__ Quat q_slerp_from_identity(const Quat b, float l) {         // SLerp(Identity, b)[l], :1312-1337
+    const Quat a = q_identity();
+    float comega = a.e * b.e + a.i * b.i + a.j * b.j + a.k * b.k;
+    const bool flip = comega < 0.0f;
+    if (flip) comega = -comega;
+    const float omega = d_acos(comega);
+    if (omega > 1e-7f) {
+        const float rs = 1.0f / d_sin(omega);
+        const float p = d_sin((1.0f - l) * omega) * rs;
+        l = d_sin(l * omega) * rs;
+        if (flip) l = -l;
+        const Quat x = q_scale(a, p), y = q_scale(b, l);
+        return {x.i + y.i, x.j + y.j, x.k + y.k, x.e + y.e};
+    }
+    return a;
+}
+__device__ __forceinline__ Mat4 q_to_matrix(const Quat q) {           // :540-563
+    const float ii = q.i * q.i, jj = q.j * q.j, kk = q.k * q.k, ij = q.i * q.j, jk = q.j * q.k, ki = q.i * q.k;
+    const float ie = q.i * q.e, je = q.j * q.e, ke = q.k * q.e;
+    Mat4 L;
+    L.m[0][0] = 1.0f - 2.0f * (jj + kk); L.m[0][1] = 2.0f * (ij + ke); L.m[0][2] = 2.0f * (ki - je); L.m[0][3] = 0.f;
+    L.m[1][0] = 2.0f * (ij - ke); L.m[1][1] = 1.0f - 2.0f * (kk + ii); L.m[1][2] = 2.0f * (jk + ie); L.m[1][3] = 0.f;
+    L.m[2][0] = 2.0f * (ki + je); L.m[2][1] = 2.0f * (jk - ie); L.m[2][2] = 1.0f - 2.0f * (ii + jj); L.m[2][3] = 0.f;
+    L.m[3][0] = 0.f; L.m[3][1] = 0.f; L.m[3][2] = 0.f; L.m[3][3] = 1.f;
+    return L;
+}
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v_normalize(const V3 v) {                // :390-400
+    const float n = 1.0f / d_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    return {v.x * n, v.y * n, v.z * n};
+}
+__device__ __forceinline__ float v_dot(const V3 a, const V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+__device__ Quat axis_to_quat(const V3 axis, float angle) {             // :1047-1058
+    const float norm = d_sqrt(axis.x * axis.x + axis.y * axis.y + axis.z * axis.z);
+    if (norm < 1e-7f) return q_identity();
+    angle *= 0.5f;
+    const float s = d_sin(angle) / norm;
+    return {s * axis.x, s * axis.y, s * axis.z, d_cos(angle)};
+}
+
+__device__ void quat_to_euler(uint32_t order, const Quat q, float *r) {   // :1059-1071, :1110-1135
+    const float ii = q.i * q.i, jj = q.j * q.j, kk = q.k * q.k;
+    const float ei = q.e * q.i, ej = q.e * q.j, ek = q.e * q.k;
+    const float ij = q.i * q.j, ik = q.i * q.k, jk = q.j * q.k;
+    if (order == kOrderZXY) {
+        r[0] = d_asin(2.0f * (ei + jk));
+        r[1] = d_atan2(2.0f * (ej - ik), 1 - 2.0f * (ii + jj));
+        r[2] = d_atan2(2.0f * (ek - ij), 1 - 2.0f * (ii + kk));
+    } else if (order == kOrderXYZ) {
+        r[0] = d_atan2(2.0f * (ei - jk), 1 - 2.0f * (ii + jj));
+        r[1] = d_asin(2.0f * (ej + ik));
+        r[2] = d_atan2(2.0f * (ek - ij), 1 - 2.0f * (jj + kk));
+    } else {
+        r[0] = d_atan2(2.0f * (ei - jk), 1 - 2.0f * (ii + kk));
+        r[1] = d_atan2(2.0f * (ej - ik), 1 - 2.0f * (jj + kk));
+        r[2] = d_asin(2.0f * (ek + ij));
+    }
+}
+__device__ Quat euler_to_quat(uint32_t order, const float *r) {           // :1137-1149, :1176-1201
+    const float cx = d_cos(r[0] * 0.5f), sx = d_sin(r[0] * 0.5f);
+    const float cy = d_cos(r[1] * 0.5f), sy = d_sin(r[1] * 0.5f);
+    const float cz = d_cos(r[2] * 0.5f), sz = d_sin(r[2] * 0.5f);
+    Quat q;
+    if (order == kOrderZXY) {
+        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz - cx * sy * sz;
+        q.j = cx * sy * cz + sx * cy * sz; q.k = cx * cy * sz + sx * sy * cz;
+    } else if (order == kOrderXYZ) {
+        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz + cx * sy * sz;
+        q.j = cx * sy * cz - sx * cy * sz; q.k = sx * sy * cz + cx * cy * sz;
+    } else {
+        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz + cx * sy * sz;
+        q.j = cx * sy * cz + sx * cy * sz; q.k = cx * cy * sz - sx * sy * cz;
+    }
+    return q;
+}
+__device__ __forceinline__ void limit_euler(float *e, const float *lo, const float *hi, bool ikt) {   // poser_impl.inl:178-194
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (e[i] < lo[i]) {
+            const float tf = 2 * lo[i] - e[i];
+            e[i] = (tf <= hi[i] && ikt) ? tf : lo[i];
+        }
+        if (e[i] > hi[i]) {
+            const float tf = 2 * hi[i] - e[i];
+            e[i] = (tf >= lo[i] && ikt) ? tf : hi[i];
+        }
+    }
+}
+
+// total rotation / translation already in the state: build local_matrix_ and apply the parent product
+__device__ void place_bone(const State &st, const BoneRec &rec, uint32_t b) {
+    Mat4 L = q_to_matrix(st.quat(b, kStTotalRot));
+    L.m[3][0] = st.at(b, kStTotalTr + 0) + rec.local_offset[0];
+    L.m[3][1] = st.at(b, kStTotalTr + 1) + rec.local_offset[1];
+    L.m[3][2] = st.at(b, kStTotalTr + 2) + rec.local_offset[2];
+    if (rec.parent >= 0) L = mul(L, st.local(uint32_t(rec.parent)));
+    st.set_local(b, L);
+}
+
+// UpdateBoneTransform up to (not including) the IK solve, poser_impl.inl:142-166
+__device__ void transform_bone(const State &st, const SerialParams &p, const float4 *pose, uint32_t b) {
+    const BoneRec rec = p.bones[b];
+    const float4 t = pose[2 * size_t(b)], r = pose[2 * size_t(b) + 1];
+    Quat total = q_mul(q_identity(), {r.x, r.y, r.z, r.w});
+    float tx = 0.f + t.x, ty = 0.f + t.y, tz = 0.f + t.z;
+    if (rec.bits & (kBoneAppendRot | kBoneAppendTr)) {
+        // the reference assigns total_rotation_ / total_translation_ before reading the append parent's,
+        // which matters when a bone names itself: keep that order
+        st.set_quat(b, kStTotalRot, total);
+        st.at(b, kStTotalTr + 0) = tx; st.at(b, kStTotalTr + 1) = ty; st.at(b, kStTotalTr + 2) = tz;
+        const uint32_t ap = uint32_t(rec.append_parent);
+        if (rec.bits & kBoneAppendRot) {
+            total = q_mul(total, q_slerp_from_identity(st.quat(ap, kStTotalRot), rec.append_ratio));
+            st.set_quat(b, kStTotalRot, total);
+        }
+        if (rec.bits & kBoneAppendTr) {
+            tx = tx + rec.append_ratio * st.at(ap, kStTotalTr + 0);
+            ty = ty + rec.append_ratio * st.at(ap, kStTotalTr + 1);
+            tz = tz + rec.append_ratio * st.at(ap, kStTotalTr + 2);
+        }
+    }
+    if (rec.bits & kBoneIsIkLink) {
+        st.set_quat(b, kStPreIkRot, total);
+        total = q_mul(st.quat(b, kStIkRot), total);
+    }
+    st.set_quat(b, kStTotalRot, total);
+    st.at(b, kStTotalTr + 0) = tx; st.at(b, kStTotalTr + 1) = ty; st.at(b, kStTotalTr + 2) = tz;
+    place_bone(st, rec, b);
+}
+
+// the CCD loop of UpdateBoneTransform, poser_impl.inl:196-309
+__device__ void solve_ik(const State &st, const SerialParams &p, const float4 *pose, uint32_t b) {
+    const IkRec ik = p.iks[p.bones[b].ik];
+    const LinkRec *links = p.links + ik.link0;
+    for (uint32_t i = 0; i < ik.nlinks; ++i) st.set_quat(links[i].bone, kStIkRot, q_identity());
+    const V3 ik_pos = {st.at(b, kStLocal + 12), st.at(b, kStLocal + 13), st.at(b, kStLocal + 14)};
+    for (uint32_t i = 0; i < ik.nlinks; ++i) transform_bone(st, p, pose, links[ik.nlinks - i - 1].bone);
+    transform_bone(st, p, pose, ik.target);
+    V3 tgt = {st.at(ik.target, kStLocal + 12), st.at(ik.target, kStLocal + 13), st.at(ik.target, kStLocal + 14)};
+    V3 err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
+    if (v_dot(err, err) < 1e-7f) return;
+    const uint32_t ikt = ik.loop / 2;
+    for (uint32_t i = 0; i < ik.loop; ++i) {
+        for (uint32_t j = 0; j < ik.nlinks; ++j) {
+            const LinkRec lk = links[j];
+            if (lk.fix == kFixAll) continue;
+            const uint32_t lb = lk.bone;
+            const BoneRec lrec = p.bones[lb];
+            const V3 lpos = {st.at(lb, kStLocal + 12), st.at(lb, kStLocal + 13), st.at(lb, kStLocal + 14)};
+            const V3 tdir = v_normalize({lpos.x - tgt.x, lpos.y - tgt.y, lpos.z - tgt.z});
+            const V3 idir = v_normalize({lpos.x - ik_pos.x, lpos.y - ik_pos.y, lpos.z - ik_pos.z});
+            V3 axis = {tdir.y * idir.z - tdir.z * idir.y, tdir.z * idir.x - tdir.x * idir.z,
+                       tdir.x * idir.y - tdir.y * idir.x};
+            if (fabsf(axis.x) < 1e-7f) axis.x = 1e-7f;
+            if (fabsf(axis.y) < 1e-7f) axis.y = 1e-7f;
+            if (fabsf(axis.z) < 1e-7f) axis.z = 1e-7f;
+            Mat4 loc;
+            if (lrec.parent >= 0) {
+                loc = st.local(uint32_t(lrec.parent));
+            } else {
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) loc.m[y][x] = x == y ? 1.f : 0.f;
+            }
+            if (lk.limited && lk.fix != kFixNone && i < ikt) {
+                const uint32_t row = lk.fix - kFixX;
+                const float d = axis.x * loc.m[row][0] + axis.y * loc.m[row][1] + axis.z * loc.m[row][2];
+                const float s = d >= 0.0f ? 1.0f : -1.0f;
+                axis = {row == 0 ? s : 0.f, row == 1 ? s : 0.f, row == 2 ? s : 0.f};
+            } else {                                       // rotate(axis, loc.Transpose()).Normalize()
+                const V3 r = {axis.x * loc.m[0][0] + axis.y * loc.m[0][1] + axis.z * loc.m[0][2],
+                              axis.x * loc.m[1][0] + axis.y * loc.m[1][1] + axis.z * loc.m[1][2],
+                              axis.x * loc.m[2][0] + axis.y * loc.m[2][1] + axis.z * loc.m[2][2]};
+                axis = v_normalize(r);
+            }
+            float dot = v_dot(tdir, idir);
+            dot = dot < -1.0f ? -1.0f : dot;               // math::clamp = min(max(x, lo), hi)
+            dot = 1.0f < dot ? 1.0f : dot;
+            const float ac = d_acos(dot), cap = ik.angle_limit * float(j + 1);
+            const float angle = cap < ac ? cap : ac;
+            Quat ikr = q_mul(axis_to_quat(axis, angle), st.quat(lb, kStIkRot));
+            if (lk.limited) {
+                const Quat pre = st.quat(lb, kStPreIkRot);
+                Quat lr = q_mul(ikr, pre);
+                float e[3];
+                quat_to_euler(lk.order, lr, e);
+                limit_euler(e, lk.lo, lk.hi, i < ikt);
+                lr = euler_to_quat(lk.order, e);
+                ikr = q_mul(lr, q_inverse(pre));
+            }
+            st.set_quat(lb, kStIkRot, ikr);
+            for (uint32_t k = 0; k <= j; ++k) {
+                const uint32_t bb = links[j - k].bone;
+                st.set_quat(bb, kStTotalRot, q_mul(st.quat(bb, kStIkRot), st.quat(bb, kStPreIkRot)));
+                place_bone(st, p.bones[bb], bb);
+            }
+            transform_bone(st, p, pose, ik.target);
+            tgt = {st.at(ik.target, kStLocal + 12), st.at(ik.target, kStLocal + 13), st.at(ik.target, kStLocal + 14)};
+        }
+        err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
+        if (v_dot(err, err) < 1e-7f) return;
+    }
+}
+
+constexpr uint32_t kSerialThreads = 64;
+
+__global__ __launch_bounds__(kSerialThreads) void skeleton_serial_kernel(const SerialParams p) {
+    const uint32_t inst = blockIdx.x * kSerialThreads + threadIdx.x;
+    if (inst >= p.ni) return;          // every lane that stays runs to the end: no barriers in this kernel
+    const State st = {p.state + inst, p.ni};
+    const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(inst) * p.nb * 2;
+    for (uint32_t b = 0; b < p.nb; ++b) {                  // PrePhysicsPosing's reset, poser_impl.inl:366-377
+        st.set_quat(b, kStTotalRot, q_identity());
+        st.set_quat(b, kStIkRot, q_identity());
+        st.set_quat(b, kStPreIkRot, q_identity());
+        st.at(b, kStTotalTr + 0) = 0.f; st.at(b, kStTotalTr + 1) = 0.f; st.at(b, kStTotalTr + 2) = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) st.at(b, kStLocal + k) = (k % 5 == 0) ? 1.f : 0.f;
+    }
+    float4 *out = reinterpret_cast<float4 *>(p.out) + size_t(inst) * p.nb * 4;
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+        const uint32_t s0 = pass ? p.n_pre : 0, s1 = pass ? p.nb : p.n_pre;
+        for (uint32_t s = s0; s < s1; ++s) {
+            const uint32_t b = p.order[s];
+            transform_bone(st, p, pose, b);
+            if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, b);
+        }
+        for (uint32_t s = s0; s < s1; ++s) {               // UpdateBoneSkinningMatrix of this list
+            const uint32_t b = p.order[s];
+            const BoneRec rec = p.bones[b];
+            Mat4 G;
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) G.m[y][x] = x == y ? 1.f : 0.f;
+            G.m[3][0] = rec.neg_rest[0]; G.m[3][1] = rec.neg_rest[1]; G.m[3][2] = rec.neg_rest[2];
+            const Mat4 S = mul(G, st.local(b));
+#pragma unroll
+            for (int y = 0; y < 4; ++y) out[4 * size_t(b) + y] = make_float4(S.m[y][0], S.m[y][1], S.m[y][2], S.m[y][3]);
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_bone_track_eval(const BoneTrackParams &p, hipStream_t stream) {
@@ -180,6 +484,13 @@ hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(skeleton_fk_kernel, dim3(uint32_t((n + kRigThreads - 1) / kRigThreads)),
                        dim3(kRigThreads), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_skeleton_serial(const SerialParams &p, hipStream_t stream) {
+    if (p.ni == 0 || p.nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(skeleton_serial_kernel, dim3((p.ni + kSerialThreads - 1) / kSerialThreads),
+                       dim3(kSerialThreads), 0, stream, p);
     return hipGetLastError();
 }
 

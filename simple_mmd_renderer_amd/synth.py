@@ -246,3 +246,88 @@ def make_bone_keys(names, seed: int, keys_per: int = 6, span: int = 240, curved:
                 ip = bytes(ip)
             keys.append((n, int(f), tuple(np.float32(t).tolist()), tuple(np.float32(q).tolist()), ip))
     return keys
+
+
+def make_ik_rig(nb: int, seed: int, n_ik: int = 4, n_append: int = 4, post_physics: float = 0.1, levels: int = 2):
+    """A random rig with CCD-IK chains and append (inherit) bones, as flat arrays:
+    (rest, parent, level, flags, append_parent i32[NB], append_ratio f32[NB], ik) with
+    ik = dict(target i32[NB] (-1 = no IK), loop i32[NB], angle f32[NB], link_off u32[NB+1],
+    link_bone i32[L], link_limited u8[L], link_lo / link_hi f32[L,3]).
+    IK bones sit near their target's rest position; links are the target's 1-3 nearest ancestors,
+    target-side first (the PMX convention); limits cover the knee-style X-only hinge, two-axis zeros,
+    all-zero (fixed) links and general boxes, so every Euler order / fix type of the reference occurs."""
+    rng = np.random.RandomState(seed)
+    rest, parent, level, flags = make_skeleton(nb, seed, 0, post_physics, levels)
+    flags = flags.copy()
+    depth = np.zeros(nb, np.int32)
+    for b in range(1, nb):
+        depth[b] = depth[parent[b]] + 1
+    target = np.full(nb, -1, np.int32)
+    loop = np.zeros(nb, np.int32)
+    angle = np.zeros(nb, np.float32)
+    links_of = {}
+    used = set()
+    cands = [b for b in range(nb) if depth[b] >= 2]
+    rng.shuffle(cands)
+    ik_bones = []
+    for t in cands:
+        if len(ik_bones) >= n_ik:
+            break
+        chain, c = [], int(parent[t])
+        for _ in range(rng.randint(1, 4)):
+            if c <= 0:
+                break
+            chain.append(c)
+            c = int(parent[c])
+        if not chain or t in used or any(x in used for x in chain):
+            continue
+        free = [b for b in range(1, nb) if b not in used and b != t and b not in chain
+                and not np.any(parent == b)]                       # a leaf becomes the IK bone
+        if not free:
+            break
+        ikb = int(free[rng.randint(len(free))])
+        used.update(chain + [t, ikb])
+        ik_bones.append(ikb)
+        flags[ikb] |= 0x0020
+        rest[ikb] = rest[t] + rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+        target[ikb] = t
+        loop[ikb] = int(rng.choice([0, 3, 15, 40, 300, -1]))
+        angle[ikb] = np.float32(rng.choice([0.03, 0.5, 2.0, 4.0]))
+        links_of[ikb] = chain
+    link_off, link_bone, link_limited, lo, hi = [0], [], [], [], []
+    kinds = ["knee", "free", "box", "fixed", "yonly", "zonly", "swapped", "ybox"]
+    for b in range(nb):
+        for lb in links_of.get(b, []):
+            kind = kinds[rng.randint(len(kinds))]
+            link_bone.append(lb)
+            link_limited.append(0 if kind == "free" else 1)
+            a, z = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            if kind == "knee":
+                a[0], z[0] = -3.1415927, -0.008726646
+            elif kind == "box":
+                a, z = rng.uniform(-1.5, -0.1, 3).astype(np.float32), rng.uniform(0.1, 1.5, 3).astype(np.float32)
+            elif kind == "yonly":
+                a[1], z[1] = -1.0, 2.0
+            elif kind == "zonly":
+                a[2], z[2] = -0.5, 0.5
+            elif kind == "swapped":                               # lo > hi: the ctor takes min / max
+                a, z = rng.uniform(0.1, 3.0, 3).astype(np.float32), rng.uniform(-3.0, -0.1, 3).astype(np.float32)
+            elif kind == "ybox":                                  # x range beyond +-pi/2 -> XYZ order
+                a[:] = (-2.0, -1.0, -3.0)
+                z[:] = (2.0, 1.0, 3.0)
+            lo.append(a)
+            hi.append(z)
+        link_off.append(len(link_bone))
+    append_parent = np.full(nb, -1, np.int32)
+    append_ratio = np.zeros(nb, np.float32)
+    plain = [b for b in range(1, nb) if b not in used]
+    rng.shuffle(plain)
+    for b in plain[:n_append]:
+        flags[b] |= int(rng.choice([0x0100, 0x0200, 0x0300]))
+        append_parent[b] = int(rng.randint(0, nb)) if rng.uniform() < 0.9 else nb + 5   # out of range = no append
+        append_ratio[b] = np.float32(rng.choice([0.5, 1.0, -1.0, 0.25, 2.0]))
+    ik = dict(target=target, loop=loop, angle=angle, link_off=np.asarray(link_off, np.uint32),
+              link_bone=np.asarray(link_bone, np.int32).reshape(-1),
+              link_limited=np.asarray(link_limited, np.uint8).reshape(-1),
+              link_lo=np.asarray(lo, np.float32).reshape(-1, 3), link_hi=np.asarray(hi, np.float32).reshape(-1, 3))
+    return rest, parent, level, flags, append_parent, append_ratio, ik

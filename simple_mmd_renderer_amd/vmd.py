@@ -202,26 +202,50 @@ class BoneMotion:
 
 class SkeletonDesc(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_bones", C.c_uint32), ("rest_position", C.c_void_p),
-                ("parent", C.c_void_p), ("transform_level", C.c_void_p), ("flags", C.c_void_p)]
+                ("parent", C.c_void_p), ("transform_level", C.c_void_p), ("flags", C.c_void_p),
+                ("append_parent", C.c_void_p), ("append_ratio", C.c_void_p),
+                ("ik_target", C.c_void_p), ("ik_loop_count", C.c_void_p), ("ik_angle_limit", C.c_void_p),
+                ("ik_link_offset", C.c_void_p), ("ik_link_bone", C.c_void_p), ("ik_link_limited", C.c_void_p),
+                ("ik_link_lo", C.c_void_p), ("ik_link_hi", C.c_void_p)]
 
 
 class SkeletonInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_bones", C.c_uint32), ("n_pre_physics", C.c_uint32),
-                ("n_post_physics", C.c_uint32), ("max_chain", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("n_post_physics", C.c_uint32), ("max_chain", C.c_uint32), ("solver", C.c_uint32),
+                ("n_ik_bones", C.c_uint32), ("n_ik_links", C.c_uint32), ("n_append_bones", C.c_uint32),
+                ("reserved0", C.c_uint32)]
+
+
+SOLVER_PARALLEL_FK, SOLVER_SERIAL = 0, 1
 
 
 class Skeleton:
     """A model's bone hierarchy compiled for the device bone solve (local poses -> float[16] palettes,
-    Poser::UpdateBoneTransform + UpdateBoneSkinningMatrix in the reference's evaluation order)."""
+    Poser::UpdateBoneTransform + UpdateBoneSkinningMatrix in the reference's evaluation order).
+    ik = dict(target, loop, angle, link_off, link_bone, link_limited, link_lo, link_hi) as produced by
+    synth.make_ik_rig / the PMX loader; None for a rig without IK."""
 
-    def __init__(self, rest_position, parent, transform_level=None, flags=None):
+    def __init__(self, rest_position, parent, transform_level=None, flags=None, append_parent=None,
+                 append_ratio=None, ik=None):
         rest = np.ascontiguousarray(rest_position, np.float32).reshape(-1, 3)
         nb = rest.shape[0]
-        par = np.ascontiguousarray(parent, np.int32).reshape(nb)
-        lvl = np.ascontiguousarray(transform_level, np.int32).reshape(nb) if transform_level is not None else None
-        flg = np.ascontiguousarray(flags, np.uint16).reshape(nb) if flags is not None else None
-        d = SkeletonDesc(C.sizeof(SkeletonDesc), nb, rest.ctypes.data, par.ctypes.data,
-                         lvl.ctypes.data if lvl is not None else None, flg.ctypes.data if flg is not None else None)
+
+        def arr(a, dt, shape=None):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            return a.reshape(shape) if shape is not None else a
+        keep = [rest, arr(parent, np.int32, nb), arr(transform_level, np.int32, nb), arr(flags, np.uint16, nb),
+                arr(append_parent, np.int32, nb), arr(append_ratio, np.float32, nb)]
+        if ik is not None:
+            keep += [arr(ik["target"], np.int32, nb), arr(ik["loop"], np.int32, nb), arr(ik["angle"], np.float32, nb),
+                     arr(ik["link_off"], np.uint32, nb + 1), arr(ik["link_bone"], np.int32), arr(ik["link_limited"], np.uint8),
+                     arr(ik["link_lo"], np.float32), arr(ik["link_hi"], np.float32)]
+        else:
+            keep += [None] * 8
+        d = SkeletonDesc(C.sizeof(SkeletonDesc), nb, *[a.ctypes.data if a is not None and a.size else
+                                                        (a.ctypes.data if a is not None else None) for a in keep])
+        self._keep = keep
         self.h = C.c_void_p()
         api.check(api.lib().mmdx_skeleton_create(C.byref(d), C.byref(self.h)))
         info = SkeletonInfo()

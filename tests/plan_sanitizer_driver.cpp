@@ -178,7 +178,42 @@ int main() {
         d.rest_position = rest.data(); d.parent = par.data();
         d.transform_level = it % 3 ? lvl.data() : nullptr; d.flags = it % 2 ? fl.data() : nullptr;
         mmdx::SkeletonPlan sp;
-        if (mmdx::build_skeleton(d, sp).empty()) {
+        std::string err;
+        // IK / append tables, with some indices out of range on purpose
+        std::vector<int32_t> app(nb + 1), tgt(nb + 1), loop(nb + 1), lbone;
+        std::vector<float> ratio(nb + 1, 0.5f), ang(nb + 1, 1.0f), lim;
+        std::vector<uint32_t> loff(nb + 2, 0);
+        std::vector<uint8_t> limited;
+        if (it % 4 == 3) {
+            for (uint32_t b = 0; b < nb; ++b) {
+                if (rng() % 6 == 0) fl[b] |= uint16_t(0x0100 << (rng() % 2));
+                if (rng() % 9 == 0) fl[b] |= 0x0020;
+                app[b] = int32_t(rng() % (nb + 3)) - 1;
+                tgt[b] = int32_t(rng() % (nb + 1));
+                loop[b] = int32_t(rng() % 400) - 50;
+                const uint32_t nl = (fl[b] & 0x0020) ? rng() % 4 : 0;
+                for (uint32_t l = 0; l < nl; ++l) {
+                    lbone.push_back(int32_t(rng() % (nb + 1)));
+                    limited.push_back(uint8_t(rng() % 2));
+                    for (int k = 0; k < 6; ++k) lim.push_back(float(int(rng() % 7) - 3));
+                }
+                loff[b + 1] = uint32_t(lbone.size());
+            }
+            d.flags = fl.data();
+            d.append_parent = app.data(); d.append_ratio = ratio.data();
+            d.ik_target = tgt.data(); d.ik_loop_count = loop.data(); d.ik_angle_limit = ang.data();
+            d.ik_link_offset = loff.data(); d.ik_link_bone = lbone.data(); d.ik_link_limited = limited.data();
+            d.ik_link_lo = lim.data(); d.ik_link_hi = lim.data() + 3;
+        }
+        if (mmdx::build_skeleton(d, sp, err) == MMDX_OK) {
+            if (sp.serial) {
+                for (const auto &r : sp.bones)
+                    if (r.parent >= int32_t(nb) || ((r.bits & 3u) && uint32_t(r.append_parent) >= nb)) return 11;
+                for (const auto &k : sp.iks) if (k.target >= nb || k.loop > 256 || k.link0 + k.nlinks > sp.links.size()) return 12;
+                for (const auto &l : sp.links) if (l.bone >= nb) return 13;
+                ++sk_ok;
+                continue;
+            }
             ++sk_ok;
             if (sp.chain_off.size() != size_t(nb) + 1 || sp.chain_off.back() != sp.chain.size()) return 9;
             for (uint32_t c : sp.chain) if (c != mmdx::kIdentityParent && c >= nb) return 10;

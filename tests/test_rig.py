@@ -140,12 +140,12 @@ def test_skeleton_create_host_side():
     sk = vmd.Skeleton(rest, parent, level, flags)
     assert sk.info["n_bones"] == 50 and sk.info["n_pre_physics"] + sk.info["n_post_physics"] == 50
     assert 1 <= sk.info["max_chain"] <= 51
-    for bad in (0x0020, 0x0100, 0x0200):
+    for bad in (0x0020, 0x0100, 0x0200):                     # IK / append flags without their arrays
         f2 = flags.copy()
         f2[7] |= bad
         with pytest.raises(api.MmdxError) as e:
             vmd.Skeleton(rest, parent, level, f2)
-        assert e.value.status == 6
+        assert e.value.status == 1 and "NULL" in str(e.value)
     p2 = parent.copy()
     p2[9] = 9
     with pytest.raises(api.MmdxError) as e:
@@ -154,6 +154,58 @@ def test_skeleton_create_host_side():
     p3 = parent.copy()
     p3[3] = 1000                                             # out of range = no parent, as in the reference
     assert vmd.Skeleton(rest, p3).info["n_bones"] == 50
+
+
+def test_ik_skeleton_create_host_side():
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(60, 3, n_ik=4, n_append=4)
+    sk = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik)
+    assert sk.info["solver"] == vmd.SOLVER_SERIAL and sk.info["n_ik_bones"] == 4
+    assert sk.info["n_ik_links"] == ik["link_bone"].size and 0 < sk.info["n_append_bones"] <= 4
+    ikb = int(np.flatnonzero(flags & 0x20)[0])
+    bad = dict(ik, target=ik["target"].copy())
+    bad["target"][ikb] = 60
+    with pytest.raises(api.MmdxError) as e:
+        vmd.Skeleton(rest, parent, level, flags, ap, ar, bad)
+    assert e.value.status == 2                               # BAD_INDEX: validated at create, never read at solve
+    bad = dict(ik, link_bone=ik["link_bone"].copy())
+    bad["link_bone"][0] = -1
+    with pytest.raises(api.MmdxError) as e:
+        vmd.Skeleton(rest, parent, level, flags, ap, ar, bad)
+    assert e.value.status == 2
+    nested = dict(ik, target=ik["target"].copy())
+    nested["target"][ikb] = int(np.flatnonzero(flags & 0x20)[1])
+    with pytest.raises(api.MmdxError) as e:
+        vmd.Skeleton(rest, parent, level, flags, ap, ar, nested)
+    assert e.value.status == 6 and "itself an IK bone" in str(e.value)
+
+
+IK_CASES = [(30, 0, 2, 2), (44, 1, 3, 4), (80, 2, 5, 6), (150, 3, 6, 10), (61, 4, 4, 0), (52, 5, 0, 8)]
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
+@pytest.mark.parametrize("nb,seed,n_ik,n_app", IK_CASES)
+def test_oracle_full_bone_solve_vs_reference(oracle, nb, seed, n_ik, n_app):
+    """Append bones + CCD-IK: the C restatement against libmmd's Poser, bit for bit."""
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, seed, n_ik=n_ik, n_append=n_app)
+    ref = Reference.skeleton(rest, parent, level, flags, ap, ar, ik)
+    moved = 0
+    for i, poses in enumerate(random_poses(4, nb, 100 + seed)):
+        got = oracle.bone_solve_full(rest, parent, poses, level, flags, ap, ar, ik)
+        gu.assert_bits_equal(got, ref.solve(poses), f"palette {i}")
+        plain = oracle.bone_solve_full(rest, parent, poses, level, flags & 0x1000)
+        moved += int(np.any(gu.bits(got) != gu.bits(plain)))
+    ref.close()
+    assert moved == 4                                        # the IK / append machinery really ran
+
+
+def test_golden_ik_rig_oracle(oracle):
+    """tests/golden/rig_ik_expect.npz: libmmd's palettes for rigs with IK chains and append bones."""
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "rig_ik_expect.npz"))
+    ik = {k[3:]: z[k] for k in z.files if k.startswith("ik_")}
+    for i in range(z["poses"].shape[0]):
+        got = oracle.bone_solve_full(z["rest"], z["parent"], z["poses"][i], z["level"], z["flags"],
+                                     z["append_parent"], z["append_ratio"], ik)
+        gu.assert_bits_equal(got, z["expect_palettes"][i], f"palette {i}")
 
 
 # ---------------------------------------------------------------------------------------- GPU ----
@@ -228,3 +280,31 @@ def test_gpu_motion_to_vertices_all_on_device(oracle):
         want_p, want_n = oracle.deform(m, rates[i], pal)
         gu.assert_bits_equal(pos[i], want_p, f"positions of instance {i}")
         gu.assert_bits_equal(nrm[i], want_n, f"normals of instance {i}")
+
+
+def _mismatch_report(got, want):
+    g, w = gu.bits(got), gu.bits(want)
+    bad = np.argwhere(g != w)
+    return bad.shape[0], (float(np.nanmax(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))))
+                          if bad.shape[0] else 0.0)
+
+
+@pytest.mark.gpu
+def test_gpu_golden_ik_rig():
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "rig_ik_expect.npz"))
+    ik = {k[3:]: z[k] for k in z.files if k.startswith("ik_")}
+    sk = vmd.Skeleton(z["rest"], z["parent"], z["level"], z["flags"], z["append_parent"], z["append_ratio"], ik)
+    assert sk.info["solver"] == vmd.SOLVER_SERIAL
+    gu.assert_bits_equal(sk.solve(z["poses"]), z["expect_palettes"], "palettes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,seed,n_ik,n_app", IK_CASES + [(300, 7, 8, 12)])
+def test_gpu_ik_skeleton_vs_oracle(oracle, nb, seed, n_ik, n_app):
+    """The serial device solver against the oracle, 70 instances (two waves, one partial)."""
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, seed, n_ik=n_ik, n_append=n_app)
+    poses = random_poses(70, nb, 200 + seed)
+    got = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik).solve(poses)
+    for i in range(poses.shape[0]):
+        want = oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, ik)
+        gu.assert_bits_equal(got[i], want, f"palette of instance {i}")
