@@ -304,6 +304,27 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
                       "cpu_reference_palettes_per_s": ni * model3.nb / secs})
             rmot.close(); rsk.close()
         out["config3_motion_to_palettes"] = c
+        # the same crowd on a rig with CCD-IK chains and append bones: the serial per-instance solver
+        rig = synth.make_ik_rig(model3.nb, 3003, n_ik=8, n_append=12, post_physics=0.0, levels=1)
+        ski = vmdmod.Skeleton(*rig)
+
+        def producer_ik():
+            bm.eval_device(ni, d_fr.ptr, d_pose.ptr, dm3)
+            ski.solve_device(ni, d_pose.ptr, d_pal.ptr, dm3)
+        ms_i = time_calls(dm3, producer_ik, 10)
+        ci = {"instances": ni, "bones": model3.nb, "ik_chains": ski.info["n_ik_bones"], "ik_links": ski.info["n_ik_links"],
+              "append_bones": ski.info["n_append_bones"], "gpu_ms_poses_plus_palettes": ms_i,
+              "gpu_palettes_per_s": ni * model3.nb / (ms_i * 1e-3)}
+        if reference_available():
+            rmot = ReferenceMotion(path)
+            rski = Reference.skeleton(rig[0], np.asarray(rig[1], np.int64), rig[2], rig[3], np.asarray(rig[4], np.int64), rig[5],
+                                      dict(rig[6], target=np.asarray(rig[6]["target"], np.int64),
+                                           link_bone=np.asarray(rig[6]["link_bone"], np.int64)))
+            secs = rmot.time_motion_solve(rski, fr_i[:128]) * (ni / 128)
+            ci.update({"cpu_reference_ms_poses_plus_palettes": secs * 1e3,
+                       "cpu_reference_palettes_per_s": ni * model3.nb / secs})
+            rmot.close(); rski.close()
+        out["config3_ik_rig_palettes"] = ci
         for b in (d_fr, d_pose, d_pal, d_w, d_a, d_b):
             b.free()
     except Exception as e:                                   # pragma: no cover - reporting only

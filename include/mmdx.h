@@ -408,6 +408,10 @@ MMDX_API mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t skeleton, mmdx_model_t 
                                          uint32_t n_instances, const float *poses, uint32_t flags,
                                          float *out_palettes);
 MMDX_API void mmdx_skeleton_destroy(mmdx_skeleton_t skeleton);
+/* Fills `desc` with pointers into `pmx` (valid until mmdx_pmx_destroy): rest positions, parents, transform
+ * levels, flag words, append and IK tables exactly as the file states them (PmxReader,
+ * L/reader/pmx_reader_impl.inl:192-264), ready for mmdx_skeleton_create(). */
+MMDX_API mmdx_status mmdx_pmx_get_skeleton_desc(mmdx_pmx_t pmx, mmdx_skeleton_desc *desc);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,11 @@ struct mmdx_pmx_s {
     std::vector<float> bone_pos;
     std::vector<int32_t> bone_parent, bone_level;
     std::vector<uint16_t> bone_flags;
+    // append (inherit) and IK data of the bone block, for mmdx_skeleton_create
+    std::vector<int32_t> append_parent, ik_target, ik_loop, ik_link_bone;
+    std::vector<float> append_ratio, ik_angle, ik_link_lo, ik_link_hi;
+    std::vector<uint32_t> ik_link_off;
+    std::vector<uint8_t> ik_link_limited;
     // morphs
     std::vector<int32_t> morph_type;
     std::vector<uint8_t> morph_panel;
@@ -229,6 +234,9 @@ void parse(mmdx_pmx_s &m, const uint8_t *data, size_t size) {
     if (nb < 0) throw ParseError{"PMX: negative bone count"};
     c.need(size_t(nb) * (8 + 12 + w_bone + 4 + 2 + w_bone), "the bone block");   // smallest possible bone record
     m.bone_pos.resize(size_t(nb) * 3); m.bone_parent.resize(nb); m.bone_level.resize(nb); m.bone_flags.resize(nb);
+    m.append_parent.assign(nb, -1); m.append_ratio.assign(nb, 0.f);
+    m.ik_target.assign(nb, -1); m.ik_loop.assign(nb, 0); m.ik_angle.assign(nb, 0.f);
+    m.ik_link_off.assign(size_t(nb) + 1, 0);
     for (int32_t i = 0; i < nb; ++i) {
         m.bone_names.push_back(c.text(utf8, "a bone"));
         c.text(utf8, "a bone");
@@ -239,20 +247,31 @@ void parse(mmdx_pmx_s &m, const uint8_t *data, size_t size) {
         const uint16_t flags = c.get<uint16_t>("a bone");
         m.bone_flags[i] = flags;
         if (flags & kBoneChildUseId) c.index(w_bone, "a bone"); else c.skip(12, "a bone");
-        if (flags & (kBoneAppendRotate | kBoneAppendTranslate)) { c.index(w_bone, "a bone"); c.skip(4, "a bone"); }
+        if (flags & (kBoneAppendRotate | kBoneAppendTranslate)) {
+            m.append_parent[i] = c.index(w_bone, "a bone");   // range-checked by mmdx_skeleton_create ("outside = none")
+            m.append_ratio[i] = c.get<float>("a bone");
+        }
         if (flags & kBoneAxisFixed) c.skip(12, "a bone");
         if (flags & kBoneLocalAxis) c.skip(24, "a bone");
         if (flags & kBoneReceiveTransform) c.skip(4, "a bone");
         if (flags & kBoneHasIk) {
-            c.index(w_bone, "a bone");
-            c.skip(8, "a bone");                     // loop count, angle limit
+            m.ik_target[i] = c.index(w_bone, "a bone");
+            m.ik_loop[i] = c.get<int32_t>("a bone");
+            m.ik_angle[i] = c.get<float>("a bone");
             const int32_t links = c.get<int32_t>("a bone");
             if (links < 0) throw ParseError{"PMX: negative IK link count"};
+            c.need(size_t(links) * (w_bone + 1), "the IK links");
             for (int32_t l = 0; l < links; ++l) {
-                c.index(w_bone, "an IK link");
-                if (c.get<int8_t>("an IK link") != 0) c.skip(24, "an IK link");
+                m.ik_link_bone.push_back(c.index(w_bone, "an IK link"));
+                const bool limited = c.get<int8_t>("an IK link") != 0;
+                m.ik_link_limited.push_back(limited ? 1 : 0);
+                float lim[6] = {0, 0, 0, 0, 0, 0};
+                if (limited) c.floats(lim, 6, "an IK link");
+                m.ik_link_lo.insert(m.ik_link_lo.end(), lim, lim + 3);
+                m.ik_link_hi.insert(m.ik_link_hi.end(), lim + 3, lim + 6);
             }
         }
+        m.ik_link_off[size_t(i) + 1] = uint32_t(m.ik_link_bone.size());
     }
 
     // ---- morphs ---------------------------------------------------------------------------------
@@ -367,6 +386,21 @@ mmdx_status mmdx_pmx_get_model_desc(mmdx_pmx_t pmx, mmdx_model_desc *d) {
     d->bone_parent = pmx->bone_parent.data();
     d->morph_type = pmx->morph_type.data(); d->morph_offset = pmx->morph_offset.data();
     d->morph_index = pmx->morph_index.data(); d->morph_value = pmx->morph_value.data();
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_pmx_get_skeleton_desc(mmdx_pmx_t pmx, mmdx_skeleton_desc *d) {
+    if (!pmx || !d) return pmx_fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(d, 0, sizeof(*d));
+    d->struct_size = sizeof(*d);
+    d->n_bones = pmx->info.n_bones;
+    d->rest_position = pmx->bone_pos.data(); d->parent = pmx->bone_parent.data();
+    d->transform_level = pmx->bone_level.data(); d->flags = pmx->bone_flags.data();
+    d->append_parent = pmx->append_parent.data(); d->append_ratio = pmx->append_ratio.data();
+    d->ik_target = pmx->ik_target.data(); d->ik_loop_count = pmx->ik_loop.data();
+    d->ik_angle_limit = pmx->ik_angle.data(); d->ik_link_offset = pmx->ik_link_off.data();
+    d->ik_link_bone = pmx->ik_link_bone.data(); d->ik_link_limited = pmx->ik_link_limited.data();
+    d->ik_link_lo = pmx->ik_link_lo.data(); d->ik_link_hi = pmx->ik_link_hi.data();
     return MMDX_OK;
 }
 

@@ -38,6 +38,7 @@ class PmxWriteOptions:
     triangles: Optional[np.ndarray] = None
     bone_names: Optional[List[str]] = None
     morph_names: Optional[List[str]] = None
+    rig: Optional[tuple] = None        # synth.make_ik_rig(...) output: levels, flag bits, append and IK records
     model_name: str = "合成モデル synthetic"
 
 
@@ -149,6 +150,25 @@ def write_pmx(m: FlatModel, opt: Optional[PmxWriteOptions] = None) -> bytes:
         text(names_b[b]); text("bone%d" % b)
         out.extend(np.asarray(m.bone_pos[b], "<f4").tobytes())
         index(int(m.bone_parent[b]), w_bone)
+        if opt.rig is not None:
+            _, _, r_level, r_flags, r_ap, r_ar, r_ik = opt.rig
+            out.extend(struct.pack("<i", int(r_level[b])))
+            flags = BONE_ROTATABLE | BONE_VISIBLE | int(r_flags[b])
+            out.extend(struct.pack("<H", flags))
+            f(0.0, 1.0, 0.0)
+            if flags & (BONE_APPEND_ROTATE | BONE_APPEND_TRANSLATE):
+                index(int(r_ap[b]), w_bone); f(r_ar[b])
+            if flags & BONE_HAS_IK:
+                index(int(r_ik["target"][b]), w_bone)
+                out.extend(struct.pack("<i", int(r_ik["loop"][b]))); f(r_ik["angle"][b])
+                l0, l1 = int(r_ik["link_off"][b]), int(r_ik["link_off"][b + 1])
+                out.extend(struct.pack("<i", l1 - l0))
+                for l in range(l0, l1):
+                    index(int(r_ik["link_bone"][l]), w_bone)
+                    out.extend(struct.pack("<b", int(r_ik["link_limited"][l])))
+                    if r_ik["link_limited"][l]:
+                        f(*r_ik["link_lo"][l]); f(*r_ik["link_hi"][l])
+            continue
         out.extend(struct.pack("<i", 0))
         flags = BONE_ROTATABLE | BONE_VISIBLE | BONE_CONTROLLABLE
         if opt.bone_flag_variety:
@@ -230,6 +250,15 @@ class PmxModel:
     name: str
     bone_names: List[str] = field(default_factory=list)
     morph_names: List[str] = field(default_factory=list)
+    append_parent: Optional[np.ndarray] = None
+    append_ratio: Optional[np.ndarray] = None
+    ik: Optional[dict] = None          # target, loop, angle, link_off, link_bone, link_limited, link_lo, link_hi
+
+    def skeleton(self):
+        """The device bone solver for this model's rig (vmd.Skeleton)."""
+        from .vmd import Skeleton
+        return Skeleton(self.flat.bone_pos, self.flat.bone_parent, self.bone_transform_level, self.bone_flags,
+                        self.append_parent, self.append_ratio, self.ik)
 
 
 class PmxInfo(C.Structure):
@@ -288,6 +317,21 @@ def load_pmx(source) -> PmxModel:
             morph_value=_arr(d.morph_value, ne * 3, f32).reshape(ne, 3),
             sdef=_arr(d.sdef_params, nv * 9, f32).reshape(nv, 9))
 
+        from .vmd import SkeletonDesc
+        sd = SkeletonDesc()
+        api.check(lib.mmdx_pmx_get_skeleton_desc(h, C.byref(sd)))
+
+        def vp(ptr, n, dtype):
+            if n == 0 or not ptr:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
+        link_off = vp(sd.ik_link_offset, nb + 1, u32)
+        nl = int(link_off[-1]) if nb else 0
+        ik = dict(target=vp(sd.ik_target, nb, i32), loop=vp(sd.ik_loop_count, nb, i32), angle=vp(sd.ik_angle_limit, nb, f32),
+                  link_off=link_off, link_bone=vp(sd.ik_link_bone, nl, i32), link_limited=vp(sd.ik_link_limited, nl, np.uint8),
+                  link_lo=vp(sd.ik_link_lo, nl * 3, f32).reshape(nl, 3), link_hi=vp(sd.ik_link_hi, nl * 3, f32).reshape(nl, 3))
+        append_parent, append_ratio = vp(sd.append_parent, nb, i32), vp(sd.append_ratio, nb, f32)
+
         def name(kind, i):
             buf = C.create_string_buffer(1024)
             api.check(lib.mmdx_pmx_get_name(h, kind, i, buf, 1024))
@@ -302,6 +346,7 @@ def load_pmx(source) -> PmxModel:
             bone_transform_level=_arr(a.bone_transform_level, nb, i32),
             bone_flags=_arr(a.bone_flags, nb, np.uint16),
             name=name(0, 0), bone_names=[name(1, i) for i in range(nb)],
-            morph_names=[name(2, i) for i in range(nm)])
+            morph_names=[name(2, i) for i in range(nm)],
+            append_parent=append_parent, append_ratio=append_ratio, ik=ik)
     finally:
         lib.mmdx_pmx_destroy(h)

@@ -12,7 +12,7 @@ import pytest
 
 from oracle.pyoracle import Reference, ReferenceMotion, reference_available
 from simple_mmd_renderer_amd import _capi as api
-from simple_mmd_renderer_amd import synth, vmd
+from simple_mmd_renderer_amd import pmx, synth, vmd
 from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer
 from tests import golden_util as gu
 
@@ -208,6 +208,54 @@ def test_golden_ik_rig_oracle(oracle):
         gu.assert_bits_equal(got, z["expect_palettes"][i], f"palette {i}")
 
 
+def rigged_pmx(nb, seed):
+    """A small PMX file whose bone block carries a synth.make_ik_rig rig."""
+    rig = synth.make_ik_rig(nb, seed, n_ik=3, n_append=4)
+    m = synth.make_model(120, nb, 2, 10, seed=seed)
+    m.bone_pos, m.bone_parent = rig[0].copy(), rig[1].astype(m.bone_parent.dtype)
+    return pmx.write_pmx(m, pmx.PmxWriteOptions(rig=rig, index_width=(0, 1, 1, 1 + seed % 2, 0, 1))), rig
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_pmx_rig_round_trip(seed):
+    data, (rest, parent, level, flags, ap, ar, ik) = rigged_pmx(40, seed)
+    pm = pmx.load_pmx(data)
+    assert np.array_equal(pm.bone_transform_level, level)
+    assert np.array_equal(pm.bone_flags & 0x1320, flags & 0x1320)
+    has_ap = (flags & 0x0300) != 0
+    want_ap = np.where(ap >= 40, ap.astype(np.int8 if pm.info["index_width"][3] == 1 else np.int16), ap)   # as stored
+    assert np.array_equal(pm.append_parent[has_ap], want_ap[has_ap]) and np.array_equal(pm.append_ratio[has_ap], ar[has_ap])
+    has_ik = (flags & 0x20) != 0
+    for k in ("target", "loop", "angle"):
+        assert np.array_equal(pm.ik[k][has_ik], ik[k][has_ik]), k
+    for k in ("link_off", "link_bone", "link_limited"):
+        assert np.array_equal(pm.ik[k], ik[k]), k
+    lim = ik["link_limited"].astype(bool)
+    assert np.array_equal(pm.ik["link_lo"][lim], ik["link_lo"][lim]) and np.array_equal(pm.ik["link_hi"][lim], ik["link_hi"][lim])
+    sk = pm.skeleton()
+    assert sk.info["solver"] == vmd.SOLVER_SERIAL and sk.info["n_ik_bones"] == int(has_ik.sum())
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_pmx_rig_through_both_readers(oracle, tmp_path, seed):
+    """The same .pmx bytes: libmmd's PmxReader + Poser vs this loader's rig arrays through the oracle."""
+    data, _ = rigged_pmx(36 + seed, seed)
+    path = tmp_path / "rig.pmx"
+    path.write_bytes(data)
+    pm = pmx.load_pmx(str(path))
+    ref = Reference.from_pmx(str(path))
+    nb = pm.flat.nb
+    for i, poses in enumerate(random_poses(3, nb, 300 + seed)):
+        for b in range(nb):
+            ref.set_bone_pose(b, poses[b, 0:3], poses[b, 4:8])
+        ref.pose()
+        got = oracle.bone_solve_full(pm.flat.bone_pos, pm.flat.bone_parent, poses, pm.bone_transform_level,
+                                     pm.bone_flags, pm.append_parent, pm.append_ratio, pm.ik)
+        gu.assert_bits_equal(got, ref.get_palette(), f"palette {i}")
+    ref.close()
+
+
 # ---------------------------------------------------------------------------------------- GPU ----
 @pytest.mark.gpu
 def test_gpu_golden_rig():
@@ -307,4 +355,17 @@ def test_gpu_ik_skeleton_vs_oracle(oracle, nb, seed, n_ik, n_app):
     got = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik).solve(poses)
     for i in range(poses.shape[0]):
         want = oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, ik)
+        gu.assert_bits_equal(got[i], want, f"palette of instance {i}")
+
+
+@pytest.mark.gpu
+def test_gpu_pmx_rig_to_palettes(oracle):
+    """.pmx bytes -> this loader -> mmdx_pmx_get_skeleton_desc -> device solve, against the oracle."""
+    data, _ = rigged_pmx(64, 5)
+    pm = pmx.load_pmx(data)
+    poses = random_poses(9, pm.flat.nb, 77)
+    got = pm.skeleton().solve(poses)
+    for i in range(poses.shape[0]):
+        want = oracle.bone_solve_full(pm.flat.bone_pos, pm.flat.bone_parent, poses[i], pm.bone_transform_level,
+                                      pm.bone_flags, pm.append_parent, pm.append_ratio, pm.ik)
         gu.assert_bits_equal(got[i], want, f"palette of instance {i}")
