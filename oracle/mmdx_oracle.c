@@ -21,6 +21,9 @@
  *   mat * vec       L/util/math_impl.inl:1032-1045 (rotate / transform)
  *   retagging       L/model/model_impl.inl:406-452 (Model::Normalize)
  *   repack          /root/reference/main.cpp:50-54, :838-859
+ *   morph tracks    L/motion/motion_impl.inl:382-424
+ *   bone tracks     L/motion/motion_impl.inl:255-319, Bezier L/util/math_impl.inl:1379-1428, NLerp :1260-1282
+ *   bone solve      L/motion/poser_impl.inl:29-109 (ctor), :142-326 (UpdateBoneTransform incl. append + CCD-IK)
  * Matrix convention: row vector, row-major float[16], translation in elements 12..14
  *   (L/util/math.inl:383-395).
  */
