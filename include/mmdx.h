@@ -224,6 +224,25 @@ MMDX_API mmdx_status mmdx_bench_store_pattern(void *out_a_device, void *out_b_de
                                               uint32_t n_vertices, uint32_t n_instances,
                                               int32_t iterations, float *avg_ms);
 
+/* Placement-aware allocation of a crowd's output arrays ([n_instances][NV] in `out_layout`; out_b stays
+ * NULL for MMDX_OUT_VERTEX32).  On MI355X the store rate of the crowd's output pattern is bimodal in WHERE
+ * the driver places the arrays (same virtual addresses, different physical backing: ~0.97 or ~0.75 of the
+ * linear-fill rate, stable for the life of the allocation; tools/alloc_probe.py, alloc_kernel_probe.py),
+ * and the deform kernel follows it.  This helper allocates, times the store-only replay of the pattern
+ * against a linear fill, and retries up to `max_tries` times (rejected placements stay allocated until it
+ * returns, so each try lands elsewhere), keeping the best placement seen.  max_tries <= 1: plain
+ * allocation.  Free both arrays with mmdx_device_free(). */
+typedef struct mmdx_placement_info {
+    uint32_t struct_size;
+    uint32_t tries;          /* allocations made                                                        */
+    uint32_t probed;         /* 0: layout / vertex count not probe-able, plain allocation               */
+    float store_GBs;         /* store-only replay on the returned arrays                                */
+    float fill_GBs;          /* linear fill of the same bytes (the yardstick)                           */
+} mmdx_placement_info;
+MMDX_API mmdx_status mmdx_crowd_output_alloc(mmdx_model_t model, uint32_t n_instances, int32_t out_layout,
+                                             uint32_t max_tries, void **out_a_device, void **out_b_device,
+                                             mmdx_placement_info *info /* may be NULL */);
+
 /* ---- PMX 2.0 loader (the data format on the input side of the path) --------------------------- */
 /* From-scratch parser for the fields the deformation path consumes; replaces, for those fields,
  * PmxReader::ReadModel (L/reader/pmx_reader_impl.inl:16-449) + FileReader (L/util/dwarf_impl.inl:29-130)

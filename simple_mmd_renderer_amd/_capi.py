@@ -99,6 +99,8 @@ SIGNATURES = {
     "mmdx_pmx_get_model_desc": (C.c_int32, [C.c_void_p, C.POINTER(ModelDesc)]),
     "mmdx_pmx_get_arrays": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mmdx_pmx_get_name": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "mmdx_crowd_output_alloc": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), C.c_void_p]),
     "mmdx_vmd_parse": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mmdx_vmd_load_file": (C.c_int32, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mmdx_vmd_destroy": (None, [C.c_void_p]),

@@ -690,25 +690,119 @@ mmdx_status mmdx_bench_fill(void *dst, size_t bytes, int32_t iters, float *avg_m
     return bench_stream_op(dst, nullptr, bytes, iters, avg_ms);
 }
 
-mmdx_status mmdx_bench_store_pattern(void *out_a, void *out_b, uint32_t n_vertices, uint32_t n_instances,
-                                     int32_t iters, float *avg_ms) {
-    if (!out_a || !out_b || !avg_ms || iters <= 0 || !n_vertices || !n_instances || (n_vertices & 3))
-        return fail(MMDX_ERR_INVALID_ARGUMENT, "bad argument (n_vertices must be a multiple of 4)");
+namespace {
+// average ms of `iters` store-pattern launches on the default stream (after one warm-up launch)
+hipError_t time_store_pattern(void *a, void *b, uint32_t nv, uint32_t ni, uint32_t bpva, uint32_t bpvb, int iters,
+                              float *avg_ms) {
     hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    hipError_t e = launch_pattern_fill(out_a, out_b, n_vertices, n_instances, nullptr);
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return e; }
+    e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters && e == hipSuccess; ++i)
-        e = launch_pattern_fill(out_a, out_b, n_vertices, n_instances, nullptr);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (e != hipSuccess) return hip_fail(e, "bench store pattern");
     *avg_ms = ms / float(iters);
+    return e;
+}
+}  // namespace
+
+mmdx_status mmdx_bench_store_pattern(void *out_a, void *out_b, uint32_t n_vertices, uint32_t n_instances,
+                                     int32_t iters, float *avg_ms) {
+    if (!out_a || !out_b || !avg_ms || iters <= 0 || !n_vertices || !n_instances || (n_vertices & 3))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "bad argument (n_vertices must be a multiple of 4)");
+    hipError_t e = time_store_pattern(out_a, out_b, n_vertices, n_instances, 12, 12, iters, avg_ms);
+    if (e != hipSuccess) return hip_fail(e, "bench store pattern");
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_t out_layout, uint32_t max_tries,
+                                    void **out_a, void **out_b, mmdx_placement_info *info) {
+    if (!m || !out_a || !out_b || !n_instances) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
+    if (m->device < 0) return fail(MMDX_ERR_NO_DEVICE, "host-only model");
+    if (info && info->struct_size != sizeof(mmdx_placement_info))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_placement_info.struct_size mismatch");
+    uint32_t bpva, bpvb;
+    switch (out_layout) {
+    case MMDX_OUT_SOA: bpva = 12; bpvb = 12; break;
+    case MMDX_OUT_VERTEX32: bpva = 32; bpvb = 0; break;
+    case MMDX_OUT_SOA_POS16: bpva = 6; bpvb = 12; break;
+    default: return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown out_layout");
+    }
+    *out_a = *out_b = nullptr;
+    HIP_TRY(hipSetDevice(m->device));
+    const uint32_t nv = m->plan.nv;
+    const size_t bytes_a = std::max<size_t>(size_t(n_instances) * nv * bpva, 16);
+    const size_t bytes_b = bpvb ? std::max<size_t>(size_t(n_instances) * nv * bpvb, 16) : 0;
+    // the replay needs every piece 16-byte aligned; otherwise (odd vertex counts) allocate without probing
+    const bool can_probe = max_tries > 1 && nv && (size_t(nv) * bpva) % 16 == 0 && (size_t(nv) * bpvb) % 16 == 0;
+    struct Cand { void *a = nullptr, *b = nullptr; float gbs = 0.f; };
+    std::vector<Cand> parked;
+    Cand best;
+    float fill_gbs = 0.f;
+    uint32_t tries = 0;
+    mmdx_status st = MMDX_OK;
+    auto release = [](Cand &c) { if (c.a) (void)hipFree(c.a); if (c.b) (void)hipFree(c.b); c.a = c.b = nullptr; };
+    for (; tries < std::max(max_tries, 1u); ) {
+        Cand c;
+        hipError_t e = hipMalloc(&c.a, bytes_a);
+        if (e == hipSuccess && bytes_b) e = hipMalloc(&c.b, bytes_b);
+        if (e != hipSuccess) {
+            release(c);
+            (void)hipGetLastError();
+            if (best.a) break;                       // out of memory while shopping: keep what we have
+            st = hip_fail(e, "hipMalloc of the crowd output arrays");
+            break;
+        }
+        ++tries;
+        if (!can_probe) { best = c; break; }
+        float ms = 0.f;
+        if (fill_gbs == 0.f) {                       // the yardstick: a linear fill of array a
+            hipEvent_t e0, e1;
+            e = hipEventCreate(&e0);
+            if (e == hipSuccess) e = hipEventCreate(&e1);
+            if (e == hipSuccess) e = launch_fill(c.a, bytes_a & ~size_t(15), nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+            for (int i = 0; i < 5 && e == hipSuccess; ++i) e = launch_fill(c.a, bytes_a & ~size_t(15), nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            if (e == hipSuccess && ms > 0.f) fill_gbs = float(double(bytes_a) * 5 / (ms * 1e-3) / 1e9);
+        }
+        if (e == hipSuccess) e = time_store_pattern(c.a, c.b, nv, n_instances, bpva, bpvb, 5, &ms);
+        if (e != hipSuccess) { release(c); st = hip_fail(e, "probing a placement of the crowd output arrays"); break; }
+        c.gbs = float(double(bytes_a + bytes_b) / (ms * 1e-3) / 1e9);
+        if (c.gbs > best.gbs) { if (best.a) parked.push_back(best); best = c; } else parked.push_back(c);
+        if (best.gbs >= 0.92f * fill_gbs) break;     // the fast mode sits at 0.96-0.99 of the fill rate, the slow ones at 0.72-0.8
+    }
+    // rejected placements stayed allocated until here, so that every new try had to land somewhere else
+    const bool freed_any = !parked.empty();
+    for (Cand &c : parked) release(c);
+    if (st != MMDX_OK) { release(best); return st; }
+    // The driver wipes freed VRAM in the background (gigabytes per rejected try), which steals HBM bandwidth
+    // from whatever runs next: replay the pattern on the chosen arrays until its rate is back where it was
+    // measured, so the caller's first launches already see a quiet memory system (bounded: ~0.25 s).
+    for (int i = 0; freed_any && can_probe && i < 150; ++i) {
+        float ms = 0.f;
+        if (time_store_pattern(best.a, best.b, nv, n_instances, bpva, bpvb, 5, &ms) != hipSuccess) break;
+        if (double(bytes_a + bytes_b) / (ms * 1e-3) / 1e9 >= 0.98 * best.gbs) break;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    *out_a = best.a;
+    *out_b = best.b;
+    if (info) {
+        info->tries = tries;
+        info->probed = can_probe ? 1u : 0u;
+        info->store_GBs = best.gbs;
+        info->fill_GBs = fill_gbs;
+    }
     return MMDX_OK;
 }
 

@@ -681,20 +681,22 @@ __global__ __launch_bounds__(kThreads) void fill_kernel(float4 *dst, size_t n) {
     if (i < n) dst[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
-// Store-only replay of the deform kernel's output pattern (SoA): workgroup = (512-vertex tile, group of
-// 16 instances) writing one 6 KiB piece into each of the two arrays per instance.  On some MI355X boxes
-// this two-array pattern runs at the linear-fill rate, on others ~25 % below it (tools/); bench.py
-// prints it as the ceiling the deform kernel can be held against on THAT box.
+// Store-only replay of the deform kernel's output pattern: workgroup = (512-vertex tile, group of 16
+// instances) writing one piece (6 KiB for SoA) into each output array per instance.  Its rate is BIMODAL
+// on MI355X: for some placements of the arrays it runs at the linear-fill rate, for others ~25 % below,
+// and the deform kernel follows it (tools/alloc_kernel_probe.py).  Used as the ceiling bench.py prints
+// and as the probe of mmdx_crowd_output_alloc().
 __global__ __launch_bounds__(kThreads) void pattern_fill_kernel(float4 *a, float4 *b, uint32_t nv,
-                                                                uint32_t ni, uint32_t ntiles) {
+                                                                uint32_t ni, uint32_t ntiles, uint32_t bpva,
+                                                                uint32_t bpvb) {
     const uint32_t tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
     const uint32_t v0 = tile * kTileVerts, nvt = min(kTileVerts, nv - v0);
-    const uint32_t piece4 = nvt * 12 / 16;          // callers pass nv % 4 == 0
+    const uint32_t pa = nvt * bpva / 16, pb = nvt * bpvb / 16;   // callers keep nv * bytes-per-vertex % 16 == 0
     const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
     for (uint32_t g = grp * 16; g < min(ni, grp * 16 + 16); ++g) {
-        const size_t base = (size_t(g) * nv + v0) * 12 / 16;
-        for (uint32_t q = threadIdx.x; q < 2 * piece4; q += kThreads) {
-            if (q < piece4) a[base + q] = v; else b[base + q - piece4] = v;
+        const size_t base_a = (size_t(g) * nv + v0) * bpva / 16, base_b = (size_t(g) * nv + v0) * bpvb / 16;
+        for (uint32_t q = threadIdx.x; q < pa + pb; q += kThreads) {
+            if (q < pa) a[base_a + q] = v; else b[base_b + q - pa] = v;
         }
     }
 }
@@ -782,10 +784,11 @@ hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenPara
     return hipGetLastError();
 }
 
-hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, hipStream_t stream) {
+hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, uint32_t bpva, uint32_t bpvb,
+                               hipStream_t stream) {
     const uint32_t ntiles = (nv + kTileVerts - 1) / kTileVerts;
     hipLaunchKernelGGL(pattern_fill_kernel, dim3(ntiles * ((ni + 15) / 16)), dim3(kThreads), 0, stream,
-                       reinterpret_cast<float4 *>(a), reinterpret_cast<float4 *>(b), nv, ni, ntiles);
+                       reinterpret_cast<float4 *>(a), reinterpret_cast<float4 *>(b), nv, ni, ntiles, bpva, bpvb);
     return hipGetLastError();
 }
 

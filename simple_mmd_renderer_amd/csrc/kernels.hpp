@@ -82,7 +82,8 @@ hipError_t launch_deform(int threads, int layout, int morph, bool f16, const Def
 hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenParams *fused,
                               hipStream_t stream);
 constexpr uint32_t kMaxFusedSlots = 8192;
-hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, hipStream_t stream);
+hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, uint32_t bpva, uint32_t bpvb,
+                               hipStream_t stream);
 hipError_t launch_flatten(const FlattenParams &p, hipStream_t stream);
 hipError_t launch_morph_track_eval(const MorphTrackParams &t, hipStream_t stream);
 hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream);

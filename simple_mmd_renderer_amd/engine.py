@@ -59,6 +59,13 @@ class DeviceBuffer:
         self.ptr = p.value
 
     @classmethod
+    def adopt(cls, ptr: int, nbytes: int) -> "DeviceBuffer":
+        """Wrap a device range allocated by the library (freed with mmdx_device_free like any other)."""
+        b = cls.__new__(cls)
+        b.nbytes, b.ptr = int(nbytes), int(ptr)
+        return b
+
+    @classmethod
     def from_numpy(cls, a: np.ndarray) -> "DeviceBuffer":
         a = np.ascontiguousarray(a)
         b = cls(a.nbytes)
@@ -219,6 +226,23 @@ class DeformModel:
         if layout == api.OUT_VERTEX32:
             return nvi * 32, 0
         return nvi * 6, nvi * 12
+
+    def alloc_outputs(self, layout: int, ni: int, max_tries: int = 16):
+        """The crowd's output arrays through mmdx_crowd_output_alloc (placement-aware on MI355X).
+        Returns (a, b or None, info dict)."""
+        class _Info(C.Structure):
+            _fields_ = [("struct_size", C.c_uint32), ("tries", C.c_uint32), ("probed", C.c_uint32),
+                        ("store_GBs", C.c_float), ("fill_GBs", C.c_float)]
+        info = _Info()
+        info.struct_size = C.sizeof(_Info)
+        pa, pb = C.c_void_p(), C.c_void_p()
+        api.check(api.lib().mmdx_crowd_output_alloc(self.h, ni, layout, max_tries, C.byref(pa), C.byref(pb),
+                                                    C.byref(info)))
+        sa, sb = self.out_sizes(layout, ni)
+        a = DeviceBuffer.adopt(pa.value, sa)
+        b = DeviceBuffer.adopt(pb.value, sb) if pb.value else None
+        return a, b, {"tries": info.tries, "probed": bool(info.probed), "store_GBs": info.store_GBs,
+                      "fill_GBs": info.fill_GBs}
 
     def deform_batched_raw(self, ni: int, weights_ptr, palettes_ptr, out_a_ptr, out_b_ptr, layout: int,
                            flags: int, pos_scale: float = 1.0) -> None:

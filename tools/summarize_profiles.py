@@ -5,9 +5,13 @@ committed under profiles/<round>/:  python tools/summarize_profiles.py gpurun_ou
                                   separate passes); bench.py reads this file for roofline.traffic
   config3_bench.json              the plain bench line of the same box
   config3_bench_under_rocprof.json the line printed while tracing (HIP-event time to compare with the trace)
+  config3_kernel_trace_timed_region.csv  per-kernel average over the LAST `steps` dispatches of the trace =
+                                  bench.py's timed region (the stats file above also averages the untimed
+                                  settle / warm-up launches, which run through the clock transient)
 """
 import collections
 import csv
+import json
 import os
 import shutil
 import sys
@@ -18,6 +22,18 @@ def main(src, dst):
     shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(dst, "config3_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "config3_bench.json"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "config3_bench_under_rocprof.json"))
+    steps = json.load(open(os.path.join(src, "bench_under_rocprof.json")))["steps"]
+    per = collections.OrderedDict()
+    with open(os.path.join(src, "kt", "kt_kernel_trace.csv"), newline="") as f:
+        for r in csv.DictReader(f):
+            per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(dst, "config3_kernel_trace_timed_region.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches_in_trace", "last_n", "avg_ns_last_n", "min_ns_last_n", "max_ns_last_n", "avg_ns_all"])
+        for k, v in per.items():
+            if "deform_kernel" in k or "morph_apply" in k:
+                t = v[-steps:]
+                w.writerow([k, len(v), len(t), sum(t) / len(t), min(t), max(t), sum(v) / len(v)])
     rows = []
     for counter, path in (("FETCH_SIZE", "pmc_fetch/fetch_counter_collection.csv"),
                           ("WRITE_SIZE", "pmc_write/write_counter_collection.csv")):
