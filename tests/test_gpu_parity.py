@@ -284,6 +284,51 @@ def test_device_resident_io_matches_host_io(oracle):
             b.free()
 
 
+@pytest.mark.parametrize("nv,layout,tries", [(4096, api.OUT_SOA, 6), (4100, api.OUT_VERTEX32, 6), (1001, api.OUT_SOA, 6),
+                                             (4096, api.OUT_SOA, 1), (2048, api.OUT_SOA_POS16, 4)])
+def test_placement_aware_output_alloc(oracle, nv, layout, tries):
+    """mmdx_crowd_output_alloc: whatever placement it settles on, the arrays are the right size, usable by
+    mmdx_deform_batched, and hold bit-exact results afterwards (the probe's fill pattern is overwritten)."""
+    m = synth.make_model(nv, 40, 4, 100, seed=61)
+    ni = 21
+    rates = synth.morph_weights(m.nm, np.arange(ni))
+    pals = synth.make_palettes(m, np.arange(ni))
+    f16 = layout == api.OUT_SOA_POS16
+    with DeformModel(m, f16_positions=f16) as dm:
+        d_a, d_b, info = dm.alloc_outputs(layout, ni, tries)
+        assert 1 <= info["tries"] <= max(tries, 1)
+        probeable = tries > 1 and all((nv * bpv) % 16 == 0 for bpv in {api.OUT_SOA: (12,), api.OUT_VERTEX32: (32,),
+                                                                        api.OUT_SOA_POS16: (6, 12)}[layout])
+        assert info["probed"] == probeable
+        if probeable:
+            assert info["store_GBs"] > 0 and info["fill_GBs"] > 0
+        assert (d_b is None) == (layout == api.OUT_VERTEX32)
+        d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
+        flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout, flags,
+                              0.1 if layout == api.OUT_VERTEX32 else 1.0)
+        dm.sync()
+        if layout == api.OUT_VERTEX32:
+            got = d_a.download((ni, nv, 8), np.float32)
+            want = dm.deform_batched(rates, pals, layout=layout, pos_scale=0.1)
+            gu.assert_bits_equal(got, want, "v32 in placed arrays vs host-io call")
+            ep, en = oracle_expect(oracle, m, rates[5], pals[5])
+            gu.assert_bits_equal(got[5, :, 3:6], en, "normals")
+        elif layout == api.OUT_SOA:
+            pos, nrm = d_a.download((ni, nv, 3), np.float32), d_b.download((ni, nv, 3), np.float32)
+            for i in (0, 9, 20):
+                ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+                gu.assert_bits_equal(pos[i], ep, "pos")
+                gu.assert_bits_equal(nrm[i], en, "nrm")
+        else:
+            want_p, want_n = dm.deform_batched(rates, pals, layout=layout)
+            assert np.array_equal(d_a.download((ni, nv, 3), np.uint16), np.asarray(want_p).view(np.uint16).reshape(ni, nv, 3))
+            gu.assert_bits_equal(d_b.download((ni, nv, 3), np.float32), want_n, "nrm")
+        for b in (d_pal, d_w, d_a, d_b):
+            if b is not None:
+                b.free()
+
+
 def test_fp16_position_variant(oracle):
     """MMDX_CREATE_F16_POSITIONS / MMDX_OUT_SOA_POS16 (config 5): base positions and morph offsets
     stored as binary16, arithmetic f32, output positions rounded to binary16 once."""
