@@ -242,10 +242,22 @@ def pmc_traffic(is_default_layout: bool):
         "source": os.path.relpath(files[-1], ROOT)}}
 
 
-def time_calls(dm, fn, iters, warm=3):
+def time_calls(dm, fn, iters, warm=3, settle_ms=60.0):
+    """Average ms per call over `iters` back-to-back calls, after `warm` calls and -- like the headline
+    measurement -- after the clock transient that follows an idle period: untimed batches until two
+    consecutive batch averages agree within 2 % or `settle_ms` of GPU time has been spent."""
     for _ in range(warm):
         fn()
     dm.sync()
+    spent, prev, stable = 0.0, None, 0
+    while spent < settle_ms and stable < 2:
+        dm.timer_start()
+        for _ in range(iters):
+            fn()
+        t = dm.timer_stop()
+        spent += t
+        stable = stable + 1 if prev is not None and abs(t / prev - 1) < 0.02 else 0
+        prev = t
     dm.timer_start()
     for _ in range(iters):
         fn()
@@ -262,8 +274,7 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     pals = synth.make_palettes(model3, frames)
     rates = synth.morph_weights(model3.nm, frames)
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
-    sa, sb = dm3.out_sizes(api.OUT_SOA, nfr)
-    d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+    d_a, d_b, _pl = dm3.alloc_outputs(api.OUT_SOA, nfr, 16)
     ms1 = time_calls(dm3, lambda: dm3.deform_batched_raw(1, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
                                                          api.OUT_SOA, flags_dev), 200)
     ms64 = time_calls(dm3, lambda: dm3.deform_batched_raw(nfr, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
@@ -455,8 +466,7 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     pals = synth.make_palettes(m5, frames)
     rates = synth.morph_weights(m5.nm, frames)
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
-    sa, sb = dm5.out_sizes(api.OUT_SOA_POS16, nfr)
-    d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+    d_a, d_b, _pl = dm5.alloc_outputs(api.OUT_SOA_POS16, nfr, 16)
     ms1 = time_calls(dm5, lambda: dm5.deform_batched_raw(1, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
                                                          api.OUT_SOA_POS16, flags_dev), 100)
     ms64 = time_calls(dm5, lambda: dm5.deform_batched_raw(nfr, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr,
