@@ -62,16 +62,21 @@ def main():
                                                 device_select, device_synchronize)
     build.build()
     api.lib()
+    # HIP first, torch second: torch bundles its own HIP runtime; if it gets to initialise before this
+    # process has touched the GPU through the system runtime libmmdx links against, the latter sees no
+    # device.  So count / select / touch the device, THEN import torch for the gloo rendezvous.
+    ndev = device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no HIP device visible -- this engine has no CPU path to fall back to")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device_select(local_rank % ndev)
+    DeviceBuffer(256).free()
     rv = Rendezvous()
-    rank, world, local_rank = rv.rank, rv.world, rv.local_rank
+    rank, world = rv.rank, rv.world
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    ndev = device_count()
-    if ndev < 1:
-        sys.exit("bench.py: no HIP device visible -- this engine has no CPU path to fall back to")
-    device_select(local_rank % ndev)
     barrier = rv.barrier
 
     # ---- workload ------------------------------------------------------------------------------
