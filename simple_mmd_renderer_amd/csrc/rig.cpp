@@ -222,6 +222,34 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
         out.bones[b].ik = uint32_t(out.iks.size());
         out.iks.push_back(ik);
     }
+    // Which chains can run on the LDS window: link j's parent is link j+1, the target hangs off link 0,
+    // all bones distinct, no append bone inside (appends read bones outside the window).
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (!(out.bones[b].bits & kBoneHasIk)) continue;
+        IkRec &ik = out.iks[out.bones[b].ik];
+        const LinkRec *lk = out.links.data() + ik.link0;
+        const uint32_t n = ik.nlinks;
+        bool ok = n >= 1 && n <= kMaxFastLinks && ik.target != b && out.bones[ik.target].parent == int32_t(lk[0].bone) &&
+                  !(out.bones[ik.target].bits & (kBoneAppendRot | kBoneAppendTr));
+        for (uint32_t j = 0; ok && j < n; ++j) {
+            if (out.bones[lk[j].bone].bits & (kBoneAppendRot | kBoneAppendTr)) ok = false;
+            if (lk[j].bone == ik.target || lk[j].bone == b) ok = false;
+            if (j + 1 < n && out.bones[lk[j].bone].parent != int32_t(lk[j + 1].bone)) ok = false;
+            for (uint32_t k = j + 1; ok && k < n; ++k) if (lk[k].bone == lk[j].bone) ok = false;
+        }
+        ik.outside_parent = -1;
+        if (ok) {
+            const int32_t op = out.bones[lk[n - 1].bone].parent;
+            for (uint32_t j = 0; j < n; ++j) if (op == int32_t(lk[j].bone)) ok = false;
+            if (op == int32_t(ik.target)) ok = false;
+            ik.outside_parent = op;
+        }
+        ik.fast = ok ? 1u : 0u;
+        if (ok) {
+            ++out.n_fast;
+            out.fast_slots = std::max(out.fast_slots, n + 2);
+        }
+    }
     out.n_ik = uint32_t(out.iks.size());
     out.n_links = uint32_t(out.links.size());
     return MMDX_OK;

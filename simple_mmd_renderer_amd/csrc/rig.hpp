@@ -62,8 +62,11 @@ struct BoneRec {                                // serial solver: everything sta
 struct IkRec {
     uint32_t target, loop, link0, nlinks;       // loop already clamped to <= 256
     float angle_limit;
-    uint32_t pad[3];
+    uint32_t fast;                              // plain chain topology: solved on an LDS window
+    int32_t outside_parent;                     // fast: parent bone of the root-most link, -1 = none
+    uint32_t pad;
 };
+constexpr uint32_t kMaxFastLinks = 6;           // (links + target + outside parent) x 31 x 64 floats <= 64 KiB
 struct LinkRec {                                // the per-link constants the Poser ctor derives (48 B)
     uint32_t bone, limited, order, fix;
     float lo[4], hi[4];                         // min / max per component, [3] unused
@@ -71,7 +74,7 @@ struct LinkRec {                                // the per-link constants the Po
 
 struct SkeletonPlan {
     uint32_t nb = 0, n_pre = 0, n_post = 0, max_chain = 0;
-    uint32_t n_ik = 0, n_links = 0, n_append = 0;
+    uint32_t n_ik = 0, n_links = 0, n_append = 0, fast_slots = 0, n_fast = 0;
     bool serial = false;                        // IK or append bones present: not a pure parent-chain FK
     std::vector<uint32_t> order;                // evaluation sequence: pre-physics sorted, then post-physics sorted
     // parallel FK
@@ -107,6 +110,7 @@ struct SerialParams {
     const IkRec *iks;
     const LinkRec *links;
     uint32_t nb, ni, n_pre;
+    uint32_t fast_slots;                        // LDS window size in bones (0: no fast chain)
 };
 
 }  // namespace mmdx

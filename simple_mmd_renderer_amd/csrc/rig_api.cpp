@@ -234,6 +234,7 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
         sp.iks = static_cast<const IkRec *>(s->iks.ptr);
         sp.links = static_cast<const LinkRec *>(s->links.ptr);
         sp.nb = pl.nb; sp.ni = n_instances; sp.n_pre = pl.n_pre;
+        sp.fast_slots = pl.fast_slots;
         HIP_TRY(launch_skeleton_serial(sp, st));
     } else {
         SkeletonParams fp;

@@ -172,34 +172,39 @@ __global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const Skeleton
 // chains and links are the same for all lanes: those records come through scalar loads.  The float
 // operation order is the reference's; sqrt/sin/cos/asin/acos/atan2 go through double and back like
 // L/util/math.inl:27-45.
+constexpr uint32_t kSerialThreads = 64;
+
 struct Quat {
     float i, j, k, e;
 };
 enum : uint32_t { kStTotalRot = 0, kStIkRot = 4, kStPreIkRot = 8, kStTotalTr = 12, kStLocal = 15 };
 
-struct State {
-    float *base;      // already offset to this lane's instance
-    size_t ni;
-    __device__ __forceinline__ float &at(uint32_t bone, uint32_t f) const {
-        return base[(size_t(bone) * kSerialStateFloats + f) * ni];
+template <typename Ptr>
+struct StateT {
+    Ptr base;         // already offset to this lane (global scratch: + instance; LDS window: + lane)
+    size_t stride;    // elements between consecutive (index, field) cells: instances in HBM, 64 lanes in LDS
+    __device__ __forceinline__ auto &at(uint32_t idx, uint32_t f) const {
+        return base[(size_t(idx) * kSerialStateFloats + f) * stride];
     }
-    __device__ __forceinline__ Quat quat(uint32_t bone, uint32_t f) const {
-        return {at(bone, f), at(bone, f + 1), at(bone, f + 2), at(bone, f + 3)};
+    __device__ __forceinline__ Quat quat(uint32_t idx, uint32_t f) const {
+        return {at(idx, f), at(idx, f + 1), at(idx, f + 2), at(idx, f + 3)};
     }
-    __device__ __forceinline__ void set_quat(uint32_t bone, uint32_t f, const Quat q) const {
-        at(bone, f) = q.i; at(bone, f + 1) = q.j; at(bone, f + 2) = q.k; at(bone, f + 3) = q.e;
+    __device__ __forceinline__ void set_quat(uint32_t idx, uint32_t f, const Quat q) const {
+        at(idx, f) = q.i; at(idx, f + 1) = q.j; at(idx, f + 2) = q.k; at(idx, f + 3) = q.e;
     }
-    __device__ __forceinline__ Mat4 local(uint32_t bone) const {
+    __device__ __forceinline__ Mat4 local(uint32_t idx) const {
         Mat4 m;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) m.m[k / 4][k % 4] = at(bone, kStLocal + k);
+        for (int k = 0; k < 16; ++k) m.m[k / 4][k % 4] = at(idx, kStLocal + k);
         return m;
     }
-    __device__ __forceinline__ void set_local(uint32_t bone, const Mat4 &m) const {
+    __device__ __forceinline__ void set_local(uint32_t idx, const Mat4 &m) const {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) at(bone, kStLocal + k) = m.m[k / 4][k % 4];
+        for (int k = 0; k < 16; ++k) at(idx, kStLocal + k) = m.m[k / 4][k % 4];
     }
 };
+using State = StateT<float *>;                                             // per-bone state in HBM scratch
+using ChainState = StateT<__attribute__((address_space(3))) float *>;      // one IK chain's bones in LDS
 
 __device__ __forceinline__ float d_sqrt(float x) { return float(sqrt(double(x))); }
 __device__ __forceinline__ float d_sin(float x) { return float(sin(double(x))); }
@@ -314,31 +319,33 @@ __device__ __forceinline__ void limit_euler(float *e, const float *lo, const flo
     }
 }
 
-// total rotation / translation already in the state: build local_matrix_ and apply the parent product
-__device__ void place_bone(const State &st, const BoneRec &rec, uint32_t b) {
-    Mat4 L = q_to_matrix(st.quat(b, kStTotalRot));
-    L.m[3][0] = st.at(b, kStTotalTr + 0) + rec.local_offset[0];
-    L.m[3][1] = st.at(b, kStTotalTr + 1) + rec.local_offset[1];
-    L.m[3][2] = st.at(b, kStTotalTr + 2) + rec.local_offset[2];
-    if (rec.parent >= 0) L = mul(L, st.local(uint32_t(rec.parent)));
-    st.set_local(b, L);
+// total rotation / translation already in the state: build local_matrix_ and apply the parent product.
+// `self` / `parent` index the state (bone ids in HBM scratch, chain slots in LDS); parent < 0 = none.
+template <class S>
+__device__ void place_at(const S &st, const BoneRec &rec, uint32_t self, int32_t parent) {
+    Mat4 L = q_to_matrix(st.quat(self, kStTotalRot));
+    L.m[3][0] = st.at(self, kStTotalTr + 0) + rec.local_offset[0];
+    L.m[3][1] = st.at(self, kStTotalTr + 1) + rec.local_offset[1];
+    L.m[3][2] = st.at(self, kStTotalTr + 2) + rec.local_offset[2];
+    if (parent >= 0) L = mul(L, st.local(uint32_t(parent)));
+    st.set_local(self, L);
 }
 
-// UpdateBoneTransform up to (not including) the IK solve, poser_impl.inl:142-166
-__device__ void transform_bone(const State &st, const SerialParams &p, const float4 *pose, uint32_t b) {
-    const BoneRec rec = p.bones[b];
-    const float4 t = pose[2 * size_t(b)], r = pose[2 * size_t(b) + 1];
+// UpdateBoneTransform up to (not including) the IK solve, poser_impl.inl:142-166.  `ap` = state index of
+// the append parent (read only when the bone appends).
+template <class S>
+__device__ void transform_at(const S &st, const BoneRec &rec, const float4 t, const float4 r, uint32_t self,
+                             int32_t parent, uint32_t ap) {
     Quat total = q_mul(q_identity(), {r.x, r.y, r.z, r.w});
     float tx = 0.f + t.x, ty = 0.f + t.y, tz = 0.f + t.z;
     if (rec.bits & (kBoneAppendRot | kBoneAppendTr)) {
         // the reference assigns total_rotation_ / total_translation_ before reading the append parent's,
         // which matters when a bone names itself: keep that order
-        st.set_quat(b, kStTotalRot, total);
-        st.at(b, kStTotalTr + 0) = tx; st.at(b, kStTotalTr + 1) = ty; st.at(b, kStTotalTr + 2) = tz;
-        const uint32_t ap = uint32_t(rec.append_parent);
+        st.set_quat(self, kStTotalRot, total);
+        st.at(self, kStTotalTr + 0) = tx; st.at(self, kStTotalTr + 1) = ty; st.at(self, kStTotalTr + 2) = tz;
         if (rec.bits & kBoneAppendRot) {
             total = q_mul(total, q_slerp_from_identity(st.quat(ap, kStTotalRot), rec.append_ratio));
-            st.set_quat(b, kStTotalRot, total);
+            st.set_quat(self, kStTotalRot, total);
         }
         if (rec.bits & kBoneAppendTr) {
             tx = tx + rec.append_ratio * st.at(ap, kStTotalTr + 0);
@@ -347,23 +354,35 @@ __device__ void transform_bone(const State &st, const SerialParams &p, const flo
         }
     }
     if (rec.bits & kBoneIsIkLink) {
-        st.set_quat(b, kStPreIkRot, total);
-        total = q_mul(st.quat(b, kStIkRot), total);
+        st.set_quat(self, kStPreIkRot, total);
+        total = q_mul(st.quat(self, kStIkRot), total);
     }
-    st.set_quat(b, kStTotalRot, total);
-    st.at(b, kStTotalTr + 0) = tx; st.at(b, kStTotalTr + 1) = ty; st.at(b, kStTotalTr + 2) = tz;
-    place_bone(st, rec, b);
+    st.set_quat(self, kStTotalRot, total);
+    st.at(self, kStTotalTr + 0) = tx; st.at(self, kStTotalTr + 1) = ty; st.at(self, kStTotalTr + 2) = tz;
+    place_at(st, rec, self, parent);
 }
 
-// the CCD loop of UpdateBoneTransform, poser_impl.inl:196-309
-__device__ void solve_ik(const State &st, const SerialParams &p, const float4 *pose, uint32_t b) {
-    const IkRec ik = p.iks[p.bones[b].ik];
-    const LinkRec *links = p.links + ik.link0;
-    for (uint32_t i = 0; i < ik.nlinks; ++i) st.set_quat(links[i].bone, kStIkRot, q_identity());
-    const V3 ik_pos = {st.at(b, kStLocal + 12), st.at(b, kStLocal + 13), st.at(b, kStLocal + 14)};
-    for (uint32_t i = 0; i < ik.nlinks; ++i) transform_bone(st, p, pose, links[ik.nlinks - i - 1].bone);
-    transform_bone(st, p, pose, ik.target);
-    V3 tgt = {st.at(ik.target, kStLocal + 12), st.at(ik.target, kStLocal + 13), st.at(ik.target, kStLocal + 14)};
+__device__ __forceinline__ void transform_bone(const State &st, const SerialParams &p, const float4 *pose, uint32_t b) {
+    const BoneRec rec = p.bones[b];
+    transform_at(st, rec, pose[2 * size_t(b)], pose[2 * size_t(b) + 1], b, rec.parent, uint32_t(rec.append_parent));
+}
+
+// The CCD loop of UpdateBoneTransform, poser_impl.inl:196-309, over a state `st` in which link j lives at
+// index lidx(j), the target at tidx, their parents at lpar(j) / tpar (< 0 = none).  Two instantiations:
+// directly on the HBM scratch (indices = bone ids), or on an LDS window holding just the chain (fast path).
+template <class S, class LIdx, class LPar>
+__device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, const IkRec &ik, const LinkRec *links,
+                    const V3 ik_pos, LIdx lidx, LPar lpar, uint32_t tidx, int32_t tpar) {
+    const BoneRec trec = p.bones[ik.target];
+    const float4 tt = pose[2 * size_t(ik.target)], tr = pose[2 * size_t(ik.target) + 1];
+    for (uint32_t i = 0; i < ik.nlinks; ++i) st.set_quat(lidx(i), kStIkRot, q_identity());
+    for (uint32_t i = 0; i < ik.nlinks; ++i) {
+        const uint32_t j = ik.nlinks - i - 1, lb = links[j].bone;
+        const BoneRec rec = p.bones[lb];
+        transform_at(st, rec, pose[2 * size_t(lb)], pose[2 * size_t(lb) + 1], lidx(j), lpar(j), uint32_t(rec.append_parent));
+    }
+    transform_at(st, trec, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
+    V3 tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
     V3 err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
     if (v_dot(err, err) < 1e-7f) return;
     const uint32_t ikt = ik.loop / 2;
@@ -371,9 +390,9 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
         for (uint32_t j = 0; j < ik.nlinks; ++j) {
             const LinkRec lk = links[j];
             if (lk.fix == kFixAll) continue;
-            const uint32_t lb = lk.bone;
-            const BoneRec lrec = p.bones[lb];
-            const V3 lpos = {st.at(lb, kStLocal + 12), st.at(lb, kStLocal + 13), st.at(lb, kStLocal + 14)};
+            const uint32_t ls = lidx(j);
+            const int32_t lp = lpar(j);
+            const V3 lpos = {st.at(ls, kStLocal + 12), st.at(ls, kStLocal + 13), st.at(ls, kStLocal + 14)};
             const V3 tdir = v_normalize({lpos.x - tgt.x, lpos.y - tgt.y, lpos.z - tgt.z});
             const V3 idir = v_normalize({lpos.x - ik_pos.x, lpos.y - ik_pos.y, lpos.z - ik_pos.z});
             V3 axis = {tdir.y * idir.z - tdir.z * idir.y, tdir.z * idir.x - tdir.x * idir.z,
@@ -382,8 +401,8 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
             if (fabsf(axis.y) < 1e-7f) axis.y = 1e-7f;
             if (fabsf(axis.z) < 1e-7f) axis.z = 1e-7f;
             Mat4 loc;
-            if (lrec.parent >= 0) {
-                loc = st.local(uint32_t(lrec.parent));
+            if (lp >= 0) {
+                loc = st.local(uint32_t(lp));
             } else {
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
@@ -393,8 +412,8 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
             if (lk.limited && lk.fix != kFixNone && i < ikt) {
                 const uint32_t row = lk.fix - kFixX;
                 const float d = axis.x * loc.m[row][0] + axis.y * loc.m[row][1] + axis.z * loc.m[row][2];
-                const float s = d >= 0.0f ? 1.0f : -1.0f;
-                axis = {row == 0 ? s : 0.f, row == 1 ? s : 0.f, row == 2 ? s : 0.f};
+                const float sgn = d >= 0.0f ? 1.0f : -1.0f;
+                axis = {row == 0 ? sgn : 0.f, row == 1 ? sgn : 0.f, row == 2 ? sgn : 0.f};
             } else {                                       // rotate(axis, loc.Transpose()).Normalize()
                 const V3 r = {axis.x * loc.m[0][0] + axis.y * loc.m[0][1] + axis.z * loc.m[0][2],
                               axis.x * loc.m[1][0] + axis.y * loc.m[1][1] + axis.z * loc.m[1][2],
@@ -406,9 +425,9 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
             dot = 1.0f < dot ? 1.0f : dot;
             const float ac = d_acos(dot), cap = ik.angle_limit * float(j + 1);
             const float angle = cap < ac ? cap : ac;
-            Quat ikr = q_mul(axis_to_quat(axis, angle), st.quat(lb, kStIkRot));
+            Quat ikr = q_mul(axis_to_quat(axis, angle), st.quat(ls, kStIkRot));
             if (lk.limited) {
-                const Quat pre = st.quat(lb, kStPreIkRot);
+                const Quat pre = st.quat(ls, kStPreIkRot);
                 Quat lr = q_mul(ikr, pre);
                 float e[3];
                 quat_to_euler(lk.order, lr, e);
@@ -416,26 +435,58 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
                 lr = euler_to_quat(lk.order, e);
                 ikr = q_mul(lr, q_inverse(pre));
             }
-            st.set_quat(lb, kStIkRot, ikr);
+            st.set_quat(ls, kStIkRot, ikr);
             for (uint32_t k = 0; k <= j; ++k) {
-                const uint32_t bb = links[j - k].bone;
-                st.set_quat(bb, kStTotalRot, q_mul(st.quat(bb, kStIkRot), st.quat(bb, kStPreIkRot)));
-                place_bone(st, p.bones[bb], bb);
+                const uint32_t jj = j - k, bs = lidx(jj);
+                st.set_quat(bs, kStTotalRot, q_mul(st.quat(bs, kStIkRot), st.quat(bs, kStPreIkRot)));
+                place_at(st, p.bones[links[jj].bone], bs, lpar(jj));
             }
-            transform_bone(st, p, pose, ik.target);
-            tgt = {st.at(ik.target, kStLocal + 12), st.at(ik.target, kStLocal + 13), st.at(ik.target, kStLocal + 14)};
+            transform_at(st, trec, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
+            tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
         }
         err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
         if (v_dot(err, err) < 1e-7f) return;
     }
 }
 
-constexpr uint32_t kSerialThreads = 64;
+// One IK bone.  Chains with the usual topology (every link's parent is the next link, the target hangs off
+// the first link, no append bones inside; IkRec::fast, decided on the host) are solved on an LDS window:
+// their few bones' state is copied in, the up-to-256-iteration loop runs at LDS latency instead of paying
+// HBM-scratch round trips for every dependent access, and the result is copied back.  Same arithmetic.
+__device__ void solve_ik(const State &st, const SerialParams &p, const float4 *pose, uint32_t b,
+                         __attribute__((address_space(3))) float *lds_lane) {
+    const IkRec ik = p.iks[p.bones[b].ik];
+    const LinkRec *links = p.links + ik.link0;
+    const V3 ik_pos = {st.at(b, kStLocal + 12), st.at(b, kStLocal + 13), st.at(b, kStLocal + 14)};
+    if (ik.fast) {
+        const ChainState cs = {lds_lane, kSerialThreads};
+        const uint32_t n = ik.nlinks;
+        const int32_t outside = ik.outside_parent;         // parent of the root-most link, outside the chain
+        auto copy = [&](uint32_t slot, uint32_t bone, bool in) {
+#pragma unroll
+            for (uint32_t f = 0; f < kSerialStateFloats; ++f) {
+                if (in) cs.at(slot, f) = st.at(bone, f); else st.at(bone, f) = cs.at(slot, f);
+            }
+        };
+        for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, true);
+        copy(n, ik.target, true);
+        if (outside >= 0) copy(n + 1, uint32_t(outside), true);
+        ccd(cs, p, pose, ik, links, ik_pos, [](uint32_t j) { return j; },
+            [&](uint32_t j) { return j + 1 < n ? int32_t(j + 1) : (outside >= 0 ? int32_t(n + 1) : -1); }, n, 0);
+        for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, false);
+        copy(n, ik.target, false);
+    } else {
+        ccd(st, p, pose, ik, links, ik_pos, [&](uint32_t j) { return links[j].bone; },
+            [&](uint32_t j) { return p.bones[links[j].bone].parent; }, ik.target, p.bones[ik.target].parent);
+    }
+}
 
 __global__ __launch_bounds__(kSerialThreads) void skeleton_serial_kernel(const SerialParams p) {
     const uint32_t inst = blockIdx.x * kSerialThreads + threadIdx.x;
     if (inst >= p.ni) return;          // every lane that stays runs to the end: no barriers in this kernel
     const State st = {p.state + inst, p.ni};
+    extern __shared__ float chain_lds[];                    // (fast_slots) x 31 x 64 floats, lane fastest
+    auto *lds_lane = (__attribute__((address_space(3))) float *)chain_lds + threadIdx.x;
     const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(inst) * p.nb * 2;
     for (uint32_t b = 0; b < p.nb; ++b) {                  // PrePhysicsPosing's reset, poser_impl.inl:366-377
         st.set_quat(b, kStTotalRot, q_identity());
@@ -451,7 +502,7 @@ __global__ __launch_bounds__(kSerialThreads) void skeleton_serial_kernel(const S
         for (uint32_t s = s0; s < s1; ++s) {
             const uint32_t b = p.order[s];
             transform_bone(st, p, pose, b);
-            if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, b);
+            if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, b, lds_lane);
         }
         for (uint32_t s = s0; s < s1; ++s) {               // UpdateBoneSkinningMatrix of this list
             const uint32_t b = p.order[s];
@@ -489,8 +540,9 @@ hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream) {
 
 hipError_t launch_skeleton_serial(const SerialParams &p, hipStream_t stream) {
     if (p.ni == 0 || p.nb == 0) return hipSuccess;
+    const size_t lds = size_t(p.fast_slots) * kSerialStateFloats * kSerialThreads * sizeof(float);
     hipLaunchKernelGGL(skeleton_serial_kernel, dim3((p.ni + kSerialThreads - 1) / kSerialThreads),
-                       dim3(kSerialThreads), 0, stream, p);
+                       dim3(kSerialThreads), lds, stream, p);
     return hipGetLastError();
 }
 
