@@ -208,6 +208,32 @@ def test_golden_ik_rig_oracle(oracle):
         gu.assert_bits_equal(got, z["expect_palettes"][i], f"palette {i}")
 
 
+def test_rig_entry_points_fail_loudly_without_gpu_or_with_bad_arguments():
+    """No CPU fallback: evaluation / solve need the HIP device; bad arguments are refused before that."""
+    import ctypes as C
+    lib = api.lib()
+    keys = synth.make_bone_keys(BONES[:3], 1, keys_per=3)
+    bm = vmd.Vmd(vmd.write_vmd(keys, [])).bind_bones(BONES[:3])
+    rest, parent, level, flags = synth.make_skeleton(3, 1)
+    sk = vmd.Skeleton(rest, parent, level, flags)
+    frames = np.zeros(2, np.uint32)
+    poses = np.zeros((2, 3, 8), np.float32)
+    pal = np.zeros((2, 3, 16), np.float32)
+    assert lib.mmdx_bone_motion_eval(bm.h, None, 0, frames.ctypes.data, 0, poses.ctypes.data) == 1   # n_instances == 0
+    assert lib.mmdx_bone_motion_eval(None, None, 2, frames.ctypes.data, 0, poses.ctypes.data) == 1
+    assert lib.mmdx_skeleton_solve(sk.h, None, 2, None, 0, pal.ctypes.data) == 1
+    bad = vmd.SkeletonDesc()
+    bad.struct_size = 8
+    h = C.c_void_p()
+    assert lib.mmdx_skeleton_create(C.byref(bad), C.byref(h)) == 1 and "struct_size" in lib.mmdx_last_error_string().decode()
+    n = C.c_int32()
+    if lib.mmdx_device_count(C.byref(n)) != 0 or n.value < 1:      # this machine has no GPU: must say so, not compute
+        for call in (lambda: bm.eval(frames), lambda: sk.solve(poses)):
+            with pytest.raises(api.MmdxError) as e:
+                call()
+            assert e.value.status == 3 and "no HIP device" in str(e.value)
+
+
 def rigged_pmx(nb, seed):
     """A small PMX file whose bone block carries a synth.make_ik_rig rig."""
     rig = synth.make_ik_rig(nb, seed, n_ik=3, n_append=4)
