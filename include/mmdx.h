@@ -356,7 +356,8 @@ MMDX_API void mmdx_morph_motion_destroy(mmdx_morph_motion_t motion);
 typedef struct mmdx_bone_motion_s *mmdx_bone_motion_t;
 typedef struct mmdx_skeleton_s *mmdx_skeleton_t;
 
-enum { MMDX_POSES_ON_DEVICE = 1u << 1 };      /* with MMDX_OUT_ON_DEVICE for mmdx_skeleton_solve      */
+enum { MMDX_POSES_ON_DEVICE = 1u << 4 };      /* with MMDX_OUT_ON_DEVICE (and MMDX_WEIGHTS_*) for
+                                                 mmdx_skeleton_solve*                                 */
 enum { MMDX_POSE_FLOATS = 8 };                /* one local pose: translation xyz, 0, quaternion xyzw  */
 
 /* Associate the motion's bone tracks with a model's bones by name (UTF-8); bones without a track keep
@@ -399,6 +400,16 @@ typedef struct mmdx_skeleton_desc {           /* e.g. straight from mmdx_pmx_get
     const int32_t *ik_link_bone;              /* [L] target-side link first                           */
     const uint8_t *ik_link_limited;           /* [L]                                                  */
     const float *ik_link_lo, *ik_link_hi;     /* [L][3] Euler limits (either order; min/max is taken) */
+    /* bone morphs (Poser::UpdateMorphTransform, MORPH_TYPE_BONE, L/motion/poser_impl.inl:347-354) -- the
+     * model's morph table as in mmdx_model_desc; only group (0) and bone (2) morphs are read.  n_morphs
+     * == 0 / NULL: no bone morphs (morph_rotation_ = identity, morph_translation_ = 0).                */
+    uint32_t n_morphs;
+    uint32_t reserved0;
+    const int32_t *morph_type;                /* [n_morphs] PMX morph type                            */
+    const uint32_t *morph_offset;             /* [n_morphs+1]                                         */
+    const uint32_t *morph_index;              /* [E] group: morph index; bone: bone index             */
+    const float *morph_value;                 /* [E][3] group: rate in [0]; bone: translation         */
+    const float *morph_rotation;              /* [E][4] bone: rotation xyzw; NULL = identity          */
 } mmdx_skeleton_desc;
 
 typedef struct mmdx_skeleton_info {
@@ -407,7 +418,7 @@ typedef struct mmdx_skeleton_info {
     uint32_t max_chain;                       /* longest parent chain (parallel solver), else 0       */
     uint32_t solver;                          /* MMDX_SOLVER_*                                        */
     uint32_t n_ik_bones, n_ik_links, n_append_bones;
-    uint32_t reserved0;
+    uint32_t n_bone_morph_entries;            /* applications of a bone-morph entry (groups expanded)  */
 } mmdx_skeleton_info;
 
 enum {
@@ -426,6 +437,14 @@ MMDX_API mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t skeleton, mmdx_skele
 MMDX_API mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t skeleton, mmdx_model_t model,
                                          uint32_t n_instances, const float *poses, uint32_t flags,
                                          float *out_palettes);
+/* The same with bone morphs applied first: morph_weights[i][n_morphs] (or one shared row with
+ * MMDX_WEIGHTS_SHARED; device pointer with MMDX_WEIGHTS_ON_DEVICE) are the raw per-frame morph rates, the
+ * ones mmdx_deform_batched takes.  Bone-morph rotations go through SLerp, i.e. through the device's double
+ * acos / sin like the reference's through the host's.  NULL weights = mmdx_skeleton_solve. */
+MMDX_API mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t skeleton, mmdx_model_t model,
+                                                 uint32_t n_instances, const float *poses,
+                                                 const float *morph_weights, uint32_t flags,
+                                                 float *out_palettes);
 MMDX_API void mmdx_skeleton_destroy(mmdx_skeleton_t skeleton);
 /* Fills `desc` with pointers into `pmx` (valid until mmdx_pmx_destroy): rest positions, parents, transform
  * levels, flag words, append and IK tables exactly as the file states them (PmxReader,

@@ -372,6 +372,30 @@ def main():
                         **{"ik_" + k: v for k, v in ik.items()})
     print(f"{'rig_ik_expect.npz':28s} 48 bones, {int((flags & 0x20).astype(bool).sum())} IK chains, 12 poses")
 
+    # Bone-morph fixture: an FK rig (parallel solver) and an IK rig (serial solver), both with bone morphs
+    # reached directly and through groups; libmmd's palettes for random poses and morph rates.
+    gm = {}
+    for tag, (nbm2, n_ik2, n_app2, sd) in {"fk": (26, 0, 0, 97), "ik": (40, 3, 4, 98)}.items():
+        rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nbm2, sd, n_ik=n_ik2, n_append=n_app2)
+        morphs = synth.make_bone_morphs(nbm2, sd + 100)
+        rg = np.random.RandomState(sd)
+        poses = np.zeros((8, nbm2, 8), np.float32)
+        poses[..., 0:3] = rg.uniform(-1.5, 1.5, (8, nbm2, 3))
+        qq = rg.normal(size=(8, nbm2, 4))
+        poses[..., 4:8] = qq / np.linalg.norm(qq, axis=-1, keepdims=True)
+        rates = rg.choice([0, 5e-8, 0.3, 1.0, 1.7, -0.5], (8, morphs["type"].size)).astype(np.float32)
+        rsk = Reference.skeleton(rest, parent, level, flags, ap, ar, ik if n_ik2 else None, morphs)
+        pals = np.stack([rsk.solve(poses[i], rates[i]) for i in range(8)])
+        rsk.close()
+        gm.update({tag + "_rest": rest, tag + "_parent": parent, tag + "_level": level, tag + "_flags": flags,
+                   tag + "_append_parent": ap, tag + "_append_ratio": ar, tag + "_poses": poses, tag + "_rates": rates,
+                   tag + "_expect_palettes": pals})
+        gm.update({tag + "_morph_" + k: v for k, v in morphs.items()})
+        if n_ik2:
+            gm.update({tag + "_ik_" + k: v for k, v in ik.items()})
+    np.savez_compressed(os.path.join(OUT, "rig_morph_expect.npz"), **gm)
+    print(f"{'rig_morph_expect.npz':28s} FK + IK rigs with bone morphs, 8 poses each")
+
     # G13 config-1 plumbing: 20 000 verts / 150 bones / 30 morphs / 600 frames, checksums only.
     cfg = synth.CONFIGS["config1_20k"]
     m = synth.make_config("config1_20k")

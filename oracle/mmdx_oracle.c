@@ -396,8 +396,8 @@ int mmdx_oracle_bone_solve(uint32_t nb, const float *rest, const int64_t *parent
  * `abs` in the ctor's limit classification is the float overload (include-order note in ref_harness). */
 typedef struct { float i, j, k, e; } quat_t;
 typedef struct {
-    quat_t total_rot, ik_rot, pre_ik_rot;
-    float total_tr[3], local[16];
+    quat_t total_rot, ik_rot, pre_ik_rot, morph_rot;
+    float total_tr[3], morph_tr[3], local[16];
 } bone_state_t;
 
 typedef struct {
@@ -630,8 +630,8 @@ static void update_bone(const solve_ctx *c, uint32_t b, int solve_ik) {
     const float *t = c->poses + 8 * (size_t)b;
     const quat_t rot = {t[4], t[5], t[6], t[7]};
     const uint16_t f = c->flags ? c->flags[b] : 0;
-    s->total_rot = q_mul(q_identity(), rot);
-    for (int k = 0; k < 3; ++k) s->total_tr[k] = 0.0f + t[k];
+    s->total_rot = q_mul(s->morph_rot, rot);
+    for (int k = 0; k < 3; ++k) s->total_tr[k] = s->morph_tr[k] + t[k];
     if ((f & 0x0300) && c->append_parent[b] >= 0 && (uint64_t)c->append_parent[b] < c->nb) {
         const bone_state_t *ap = &c->st[c->append_parent[b]];
         if (f & 0x0100) s->total_rot = q_mul(s->total_rot, q_slerp_from_identity(ap->total_rot, c->append_ratio[b]));
@@ -645,15 +645,45 @@ static void update_bone(const solve_ctx *c, uint32_t b, int solve_ik) {
     if (solve_ik && (f & 0x0020)) solve_ik_chain(c, b);
 }
 
+/* Bone morphs: Poser::UpdateMorphTransform restricted to its effect on the bones
+ * (L/motion/poser_impl.inl:328-339 group recursion, :347-354 bone morphs). */
+typedef struct {
+    uint32_t nm;
+    const int32_t *type;
+    const uint32_t *off, *index;
+    const float *value, *rotation;
+    bone_state_t *st;
+} bmorph_ctx;
+
+static void apply_bone_morph(const bmorph_ctx *c, uint32_t m, float rate) {
+    if (rate < (float)MMDX_EPS_D) return;
+    if (c->type[m] == 0) {
+        for (uint32_t e = c->off[m]; e < c->off[m + 1]; ++e) apply_bone_morph(c, c->index[e], c->value[3 * (size_t)e] * rate);
+    } else if (c->type[m] == 2) {
+        for (uint32_t e = c->off[m]; e < c->off[m + 1]; ++e) {
+            bone_state_t *s = &c->st[c->index[e]];
+            for (int k = 0; k < 3; ++k) s->morph_tr[k] = s->morph_tr[k] + c->value[3 * (size_t)e + k] * rate;
+            quat_t r = q_identity();
+            if (c->rotation) { r.i = c->rotation[4 * (size_t)e]; r.j = c->rotation[4 * (size_t)e + 1];
+                               r.k = c->rotation[4 * (size_t)e + 2]; r.e = c->rotation[4 * (size_t)e + 3]; }
+            s->morph_rot = q_mul(s->morph_rot, q_slerp_from_identity(r, rate));
+        }
+    }
+}
+
 /* Everything as flat arrays (NULL allowed where no bone uses it): append_parent / append_ratio [NB];
  * ik_target [NB], ik_loop [NB], ik_angle [NB], ik_link_off [NB+1], ik_link_bone / ik_link_limited [L],
- * ik_link_lo / ik_link_hi [L][3].  scratch = NB * (sizeof(bone_state_t) + 5) bytes.  Returns -1 when an IK
- * link or target is itself an IK bone (recursive solves are not restated) or an index is out of range. */
+ * ik_link_lo / ik_link_hi [L][3]; morph table (nm, type, off, index, value[E][3], rotation[E][4] or NULL) with
+ * rates[nm] or nm == 0.  scratch = NB * (sizeof(bone_state_t) + 5) bytes.  Returns -1 when an IK link or
+ * target is itself an IK bone (recursive solves are not restated) or an index is out of range. */
 int mmdx_oracle_bone_solve_full(uint32_t nb, const float *rest, const int64_t *parent, const int32_t *level,
                                 const uint16_t *flags, const int64_t *append_parent, const float *append_ratio,
                                 const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
                                 const uint32_t *ik_link_off, const int64_t *ik_link_bone,
                                 const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi,
+                                uint32_t nm, const int32_t *morph_type, const uint32_t *morph_off,
+                                const uint32_t *morph_index, const float *morph_value, const float *morph_rotation,
+                                const float *rates,
                                 const float *poses, float *out, void *scratch) {
     bone_state_t *st = (bone_state_t *)scratch;
     uint32_t *order = (uint32_t *)(st + nb);
@@ -688,9 +718,14 @@ int mmdx_oracle_bone_solve_full(uint32_t nb, const float *rest, const int64_t *p
         if (pass == 0) n_pre = n;
     }
     for (uint32_t b = 0; b < nb; ++b) {
-        st[b].total_rot = st[b].ik_rot = st[b].pre_ik_rot = q_identity();
+        st[b].total_rot = st[b].ik_rot = st[b].pre_ik_rot = st[b].morph_rot = q_identity();
         st[b].total_tr[0] = st[b].total_tr[1] = st[b].total_tr[2] = 0.0f;
+        st[b].morph_tr[0] = st[b].morph_tr[1] = st[b].morph_tr[2] = 0.0f;
         mat_identity(st[b].local);
+    }
+    if (nm) {
+        const bmorph_ctx mc = {nm, morph_type, morph_off, morph_index, morph_value, morph_rotation, st};
+        for (uint32_t m = 0; m < nm; ++m) apply_bone_morph(&mc, m, rates[m]);
     }
     const solve_ctx c = {nb, rest, parent, append_parent, ik_target, ik_link_bone, flags, append_ratio, ik_angle,
                          ik_link_lo, ik_link_hi, ik_loop, ik_link_off, ik_link_limited, is_link, poses, st};

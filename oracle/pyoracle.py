@@ -144,7 +144,7 @@ class Oracle:
         return out
 
     def bone_solve_full(self, rest, parent, poses, level=None, flags=None, append_parent=None, append_ratio=None,
-                        ik=None):
+                        ik=None, morphs=None, rates=None):
         """The whole bone solve incl. append bones and CCD-IK: poses f32 [NB,8] -> palette f32 [NB,16]."""
         rest = _c(rest, np.float32).reshape(-1, 3)
         nb = rest.shape[0]
@@ -156,10 +156,14 @@ class Oracle:
         types = [C.c_float, C.c_int64, C.c_int32, C.c_uint16, C.c_int64, C.c_float] + IK_TYPES
         poses = _c(poses, np.float32).reshape(nb, 8)
         out = np.zeros((nb, 16), np.float32)
-        scratch = np.zeros(nb * 140 + 64, np.uint8)
+        scratch = np.zeros(nb * 180 + 64, np.uint8)
+        nm, marr = morph_arrays(morphs if rates is not None else None)
+        r = _c(rates, np.float32).reshape(nm) if nm else None
         self.lib.mmdx_oracle_bone_solve_full.restype = C.c_int
         rc = self.lib.mmdx_oracle_bone_solve_full(
             C.c_uint32(nb), *[_p(a, t) if a is not None else None for a, t in zip(arrs, types)],
+            C.c_uint32(nm), *[_p(a, t) if a is not None else None for a, t in zip(marr, MORPH_TYPES)],
+            _p(r, C.c_float) if r is not None else None,
             _p(poses, C.c_float), _p(out, C.c_float), scratch.ctypes.data_as(C.c_void_p))
         if rc != 0:
             raise ValueError("oracle bone solve: nested IK or an index out of range")
@@ -195,6 +199,19 @@ def ik_arrays(ik):
     return [_c(ik["target"], np.int64), _c(ik["loop"], np.int32), _c(ik["angle"], np.float32),
             _c(ik["link_off"], np.uint32), _c(ik["link_bone"], np.int64), _c(ik["link_limited"], np.uint8),
             _c(ik["link_lo"], np.float32), _c(ik["link_hi"], np.float32)]
+
+
+MORPH_TYPES = [C.c_int32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+
+
+def morph_arrays(morphs):
+    """(nm, [type, offset, index, value, rotation]) of a morph-table dict, or (0, five Nones)."""
+    if morphs is None:
+        return 0, [None] * 5
+    nm = int(np.asarray(morphs["type"]).size)
+    rot = morphs.get("rotation")
+    return nm, [_c(morphs["type"], np.int32), _c(morphs["offset"], np.uint32), _c(morphs["index"], np.uint32),
+                _c(morphs["value"], np.float32), _c(rot, np.float32) if rot is not None else None]
 
 
 def reference_available() -> bool:
@@ -273,7 +290,8 @@ class Reference:
             _p(k[12], C.c_float), C.c_int(1 if normalize else 0)))
 
     @classmethod
-    def skeleton(cls, rest, parent, level=None, flags=None, append_parent=None, append_ratio=None, ik=None) -> "Reference":
+    def skeleton(cls, rest, parent, level=None, flags=None, append_parent=None, append_ratio=None, ik=None,
+                 morphs=None) -> "Reference":
         """Bones-only libmmd model + Poser, for the bone solve (set_bone_pose / pose / get_palette).
         ik = dict(target i64[NB], loop i32[NB], angle f32[NB], link_off u32[NB+1], link_bone i64[L],
         link_limited u8[L], link_lo f32[L,3], link_hi f32[L,3]) or None."""
@@ -292,21 +310,26 @@ class Reference:
         types = [C.c_float, C.c_int64, C.c_int32, C.c_uint16, C.c_int64, C.c_float]
         keep += ik_arrays(ik)
         types += IK_TYPES
+        nm, marr = morph_arrays(morphs)
         h = lib.mmdref_create_skeleton(C.c_uint32(nb), *[_p(a, t) if a is not None else None
-                                                         for a, t in zip(keep, types)])
+                                                         for a, t in zip(keep, types)],
+                                       C.c_uint32(nm), *[_p(a, t) if a is not None else None
+                                                         for a, t in zip(marr, MORPH_TYPES)])
+        keep += marr
         self.lib, self._keep, self.h = lib, keep, C.c_void_p(h)
 
         class _Dims:
             pass
         self.model = _Dims()
-        self.model.nv, self.model.nb, self.model.nm = 0, nb, 0
+        self.model.nv, self.model.nb, self.model.nm = 0, nb, nm
         return self
 
-    def solve(self, poses):
-        """ResetPosing-equivalent state + the given local poses [NB,8] -> palette [NB,16]."""
+    def solve(self, poses, rates=None):
+        """ResetPosing-equivalent state + the given local poses [NB,8] (+ morph rates [NM]) -> palette [NB,16]."""
         poses = _c(poses, np.float32).reshape(self.model.nb, 8)
         for b in range(self.model.nb):
             self.set_bone_pose(b, poses[b, 0:3], poses[b, 4:8])
+        self.set_morphs(rates if rates is not None else np.zeros(self.model.nm, np.float32))
         self.pose()
         return self.get_palette()
 

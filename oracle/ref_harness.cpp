@@ -286,7 +286,9 @@ void *mmdref_create_skeleton(uint32_t nb, const float *bone_pos, const int64_t *
                              const int64_t *append_parent, const float *append_ratio,
                              const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
                              const uint32_t *ik_link_off, const int64_t *ik_link_bone,
-                             const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi) {
+                             const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi,
+                             uint32_t nm, const int32_t *morph_type, const uint32_t *morph_off,
+                             const uint32_t *morph_index, const float *morph_value, const float *morph_rotation) {
     Ref *r = new Ref;
     mmd::Model &m = r->model;
     m.SetExtraUVNumber(0);
@@ -319,6 +321,26 @@ void *mmdref_create_skeleton(uint32_t nb, const float *bone_pos, const int64_t *
             bone.SetAppendRatio(append_ratio[b]);
         }
         bone.SetPostPhysics((f & 0x1000) != 0);
+    }
+    // group (0) and bone (2) morphs; every other type gets an empty vertex morph so that indices keep their meaning
+    for (uint32_t k = 0; k < nm; ++k) {
+        mmd::Model::Morph &morph = m.NewMorph();
+        morph.SetName(L"m" + std::to_wstring(k));
+        const bool used = morph_type[k] == 0 || morph_type[k] == 2;
+        morph.SetType(used ? mmd::Model::Morph::MorphType(morph_type[k]) : mmd::Model::Morph::MORPH_TYPE_VERTEX);
+        for (uint32_t e = morph_off[k]; used && e < morph_off[k + 1]; ++e) {
+            mmd::Model::Morph::MorphData &md = morph.NewMorphData();
+            if (morph_type[k] == 0) {
+                md.GetGroupMorph().SetMorphIndex(size_t(morph_index[e]));
+                md.GetGroupMorph().SetMorphRate(morph_value[3 * e]);
+            } else {
+                md.GetBoneMorph().SetBoneIndex(size_t(morph_index[e]));
+                md.GetBoneMorph().SetTranslation(V3(morph_value + 3 * e));
+                mmd::Vector4f rot;
+                for (int c = 0; c < 4; ++c) rot.v[c] = morph_rotation ? morph_rotation[4 * e + c] : (c == 3 ? 1.f : 0.f);
+                md.GetBoneMorph().SetRotation(rot);
+            }
+        }
     }
     r->poser = new mmd::Poser(r->model);
     return r;

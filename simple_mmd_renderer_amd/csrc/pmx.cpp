@@ -132,6 +132,7 @@ struct mmdx_pmx_s {
     std::vector<uint8_t> morph_panel;
     std::vector<uint32_t> morph_offset, morph_index;
     std::vector<float> morph_value;
+    std::vector<float> morph_rotation;     // [E][4]: bone-morph rotation, (0,0,0,1) for every other entry
 };
 
 namespace {
@@ -287,7 +288,7 @@ void parse(mmdx_pmx_s &m, const uint8_t *data, size_t size) {
         if (count < 0) throw ParseError{"PMX: negative morph offset count"};
         m.morph_type.push_back(type);
         for (int32_t j = 0; j < count; ++j) {
-            float v[3] = {0.f, 0.f, 0.f};
+            float v[3] = {0.f, 0.f, 0.f}, rot[4] = {0.f, 0.f, 0.f, 1.f};
             int32_t idx = 0;
             if (type == MMDX_MORPH_GROUP) {
                 idx = c.index(w_morph, "a group morph");
@@ -297,8 +298,8 @@ void parse(mmdx_pmx_s &m, const uint8_t *data, size_t size) {
                 c.floats(v, 3, "a vertex morph");
             } else if (type == MMDX_MORPH_BONE) {
                 idx = c.index(w_bone, "a bone morph");
-                c.floats(v, 3, "a bone morph");      // translation; the rotation quaternion is host business
-                c.skip(16, "a bone morph");
+                c.floats(v, 3, "a bone morph");      // translation
+                c.floats(rot, 4, "a bone morph");    // rotation quaternion: consumed by the bone solve only
             } else if (type >= MMDX_MORPH_UV && type <= 7) {
                 idx = c.index(w_vertex, "a uv morph");
                 c.floats(v, 3, "a uv morph");
@@ -311,6 +312,7 @@ void parse(mmdx_pmx_s &m, const uint8_t *data, size_t size) {
             }
             m.morph_index.push_back(uint32_t(idx));
             m.morph_value.insert(m.morph_value.end(), v, v + 3);
+            m.morph_rotation.insert(m.morph_rotation.end(), rot, rot + 4);
         }
         m.morph_offset.push_back(uint32_t(m.morph_index.size()));
     }
@@ -401,6 +403,10 @@ mmdx_status mmdx_pmx_get_skeleton_desc(mmdx_pmx_t pmx, mmdx_skeleton_desc *d) {
     d->ik_angle_limit = pmx->ik_angle.data(); d->ik_link_offset = pmx->ik_link_off.data();
     d->ik_link_bone = pmx->ik_link_bone.data(); d->ik_link_limited = pmx->ik_link_limited.data();
     d->ik_link_lo = pmx->ik_link_lo.data(); d->ik_link_hi = pmx->ik_link_hi.data();
+    d->n_morphs = pmx->info.n_morphs;
+    d->morph_type = pmx->morph_type.data(); d->morph_offset = pmx->morph_offset.data();
+    d->morph_index = pmx->morph_index.data(); d->morph_value = pmx->morph_value.data();
+    d->morph_rotation = pmx->morph_rotation.data();
     return MMDX_OK;
 }
 

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 
 namespace mmdx {
@@ -129,6 +130,53 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
             out.neg_rest[4 * size_t(b) + k] = -pos[k];
         }
     }
+    // ---- bone morphs: flatten the group recursion into applications in the reference's order
+    // (top-level morph index ascending, groups expanded depth-first in place, entries in file order) --------
+    if (d.n_morphs) {
+        if (!d.morph_type || !d.morph_offset) return bad(MMDX_ERR_INVALID_ARGUMENT, "n_morphs > 0 but morph_type / morph_offset is NULL");
+        const uint32_t nm = d.n_morphs;
+        out.nm = nm;
+        for (uint32_t m = 0; m < nm; ++m)
+            if (d.morph_offset[m + 1] < d.morph_offset[m]) return bad(MMDX_ERR_INVALID_ARGUMENT, "morph_offset is not ascending");
+        if (d.morph_offset[nm] && (!d.morph_index || !d.morph_value)) return bad(MMDX_ERR_INVALID_ARGUMENT, "morph_index / morph_value is NULL");
+        std::vector<float> chain;                            // sub-rates on the current recursion path
+        std::vector<uint8_t> on_path(nm, 0);
+        std::string rec_err;
+        mmdx_status rec_st = MMDX_OK;
+        // returns false on error
+        std::function<bool(uint32_t, uint32_t)> visit = [&](uint32_t top, uint32_t m) -> bool {
+            if (on_path[m]) { rec_st = MMDX_ERR_UNSUPPORTED; rec_err = "group morph " + std::to_string(m) + " contains itself"; return false; }
+            const int32_t type = d.morph_type[m];
+            if (type != 0 && type != 2) return true;
+            on_path[m] = 1;
+            for (uint32_t e = d.morph_offset[m]; e < d.morph_offset[m + 1]; ++e) {
+                const uint32_t idx = d.morph_index[e];
+                if (type == 0) {
+                    if (idx >= nm) { rec_st = MMDX_ERR_BAD_INDEX; rec_err = "group morph " + std::to_string(m) + " refers to morph " + std::to_string(idx); return false; }
+                    chain.push_back(d.morph_value[3 * size_t(e)]);
+                    const bool ok = visit(top, idx);
+                    chain.pop_back();
+                    if (!ok) return false;
+                } else {
+                    if (idx >= nb) { rec_st = MMDX_ERR_BAD_INDEX; rec_err = "bone morph " + std::to_string(m) + " refers to bone " + std::to_string(idx); return false; }
+                    BoneMorphApp a = BoneMorphApp();
+                    a.bone = idx; a.top = top;
+                    a.chain_off = uint32_t(out.app_chain.size()); a.chain_len = uint32_t(chain.size());
+                    out.app_chain.insert(out.app_chain.end(), chain.begin(), chain.end());
+                    for (int k = 0; k < 3; ++k) a.tr[k] = d.morph_value[3 * size_t(e) + k];
+                    if (d.morph_rotation) for (int k = 0; k < 4; ++k) a.rot[k] = d.morph_rotation[4 * size_t(e) + k];
+                    else a.rot[3] = 1.0f;
+                    out.apps.push_back(a);
+                    if (out.apps.size() > (size_t(1) << 22)) { rec_st = MMDX_ERR_UNSUPPORTED; rec_err = "bone morphs expand to more than 4M applications"; return false; }
+                }
+            }
+            on_path[m] = 0;
+            return true;
+        };
+        for (uint32_t m = 0; m < nm; ++m)
+            if (!visit(m, m)) return bad(rec_st, rec_err);
+    }
+
     if (!out.serial) {
         // Parent chains.  A parent that comes LATER in the evaluation sequence still holds the identity
         // its local matrix was reset to (PrePhysicsPosing, poser_impl.inl:371): the chain then starts with

@@ -72,8 +72,19 @@ struct LinkRec {                                // the per-link constants the Po
     float lo[4], hi[4];                         // min / max per component, [3] unused
 };
 
+struct BoneMorphApp {                           // one application of a bone-morph entry, reference order (48 B)
+    uint32_t bone, top;                         // target bone; top-level morph whose rate starts the chain
+    uint32_t chain_off, chain_len;              // group sub-rates multiplied on the way down
+    float tr[3];
+    float pad;
+    float rot[4];
+};
+
 struct SkeletonPlan {
     uint32_t nb = 0, n_pre = 0, n_post = 0, max_chain = 0;
+    uint32_t nm = 0;                            // morphs of the model (row length of the rates)
+    std::vector<BoneMorphApp> apps;             // bone-morph applications in UpdateMorphTransform order
+    std::vector<float> app_chain;               // group sub-rates
     uint32_t n_ik = 0, n_links = 0, n_append = 0, fast_slots = 0, n_fast = 0;
     bool serial = false;                        // IK or append bones present: not a pure parent-chain FK
     std::vector<uint32_t> order;                // evaluation sequence: pre-physics sorted, then post-physics sorted
@@ -91,7 +102,18 @@ struct SkeletonPlan {
 // status: MMDX_OK, or the error code with its text in `err`.
 mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::string &err);
 
+constexpr uint32_t kMorphStateFloats = 7;       // morph_translation_ xyz, morph_rotation_ ijke
+
+struct BoneMorphParams {
+    const BoneMorphApp *apps;
+    const float *chain;
+    const float *rates;                         // [ni or 1][nm]
+    float *out;                                 // [nb][7][ni], instance fastest
+    uint32_t napps, nb, ni, nm, shared;
+};
+
 struct SkeletonParams {
+    const float *morph;                         // [nb][7][ni] or nullptr (no bone morphs)
     const float *poses;                         // [ni][nb][8]
     float *out;                                 // [ni][nb][16] row-major, row-vector convention
     const float *local_offset, *neg_rest;       // float4 per bone
@@ -102,6 +124,7 @@ struct SkeletonParams {
 constexpr uint32_t kSerialStateFloats = 4 + 4 + 4 + 3 + 16;   // total_rot, ik_rot, pre_ik_rot, total_tr, local
 
 struct SerialParams {
+    const float *morph;                         // [nb][7][ni] or nullptr (no bone morphs)
     const float *poses;                         // [ni][nb][8]
     float *out;                                 // [ni][nb][16]
     float *state;                               // [nb][kSerialStateFloats][ni] scratch, instance fastest

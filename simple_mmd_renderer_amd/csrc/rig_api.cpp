@@ -61,8 +61,10 @@ struct mmdx_skeleton_s {
     int device = -1;
     Buf local_offset, neg_rest, chain_off, chain, poses_in, out;
     Buf order, bones, iks, links, state;                  // serial solver
+    Buf apps, app_chain, rates_in, morph_state;           // bone morphs
     void release_all() {
-        for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &state})
+        for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &state,
+                       &apps, &app_chain, &rates_in, &morph_state})
             b->release();
     }
 };
@@ -181,12 +183,18 @@ mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t s, mmdx_skeleton_info *info) 
     info->n_ik_bones = s->plan.n_ik;
     info->n_ik_links = s->plan.n_links;
     info->n_append_bones = s->plan.n_append;
-    info->reserved0 = 0;
+    info->n_bone_morph_entries = uint32_t(s->plan.apps.size());
     return MMDX_OK;
 }
 
 mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances, const float *poses,
                                 uint32_t flags, float *out_palettes) {
+    return mmdx_skeleton_solve_morphed(s, model, n_instances, poses, nullptr, flags, out_palettes);
+}
+
+mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances,
+                                        const float *poses, const float *morph_weights, uint32_t flags,
+                                        float *out_palettes) {
     if (!s || !poses || !out_palettes || !n_instances)
         return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
     int device;
@@ -195,6 +203,8 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
     const SkeletonPlan &pl = s->plan;
     if (s->device != device) {
         s->release_all();
+        HIP_TRY(s->apps.upload(pl.apps));
+        HIP_TRY(s->app_chain.upload(pl.app_chain));
         if (pl.serial) {
             HIP_TRY(s->order.upload(pl.order));
             HIP_TRY(s->bones.upload(pl.bones));
@@ -224,9 +234,33 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
         HIP_TRY(s->out.ensure(out_bytes));
         p.out = static_cast<float *>(s->out.ptr);
     }
+    // bone morphs first: per-bone morph_translation_ / morph_rotation_ of every instance
+    const float *morph_state = nullptr;
+    bool borrowed_rates = false;
+    if (morph_weights && !pl.apps.empty()) {
+        const bool shared = (flags & MMDX_WEIGHTS_SHARED) != 0;
+        const size_t rate_bytes = size_t(shared ? 1 : n_instances) * pl.nm * sizeof(float);
+        BoneMorphParams mp;
+        if (flags & MMDX_WEIGHTS_ON_DEVICE) {
+            mp.rates = morph_weights;
+        } else {
+            HIP_TRY(s->rates_in.ensure(rate_bytes));
+            HIP_TRY(hipMemcpyAsync(s->rates_in.ptr, morph_weights, rate_bytes, hipMemcpyHostToDevice, st));
+            mp.rates = static_cast<const float *>(s->rates_in.ptr);
+            borrowed_rates = true;
+        }
+        HIP_TRY(s->morph_state.ensure(size_t(n_instances) * pl.nb * kMorphStateFloats * sizeof(float)));
+        mp.apps = static_cast<const BoneMorphApp *>(s->apps.ptr);
+        mp.chain = static_cast<const float *>(s->app_chain.ptr);
+        mp.out = static_cast<float *>(s->morph_state.ptr);
+        mp.napps = uint32_t(pl.apps.size()); mp.nb = pl.nb; mp.ni = n_instances; mp.nm = pl.nm; mp.shared = shared ? 1u : 0u;
+        HIP_TRY(launch_bone_morph(mp, st));
+        morph_state = mp.out;
+    }
     if (pl.serial) {
         HIP_TRY(s->state.ensure(size_t(n_instances) * pl.nb * kSerialStateFloats * sizeof(float)));
         SerialParams sp;
+        sp.morph = morph_state;
         sp.poses = p.poses; sp.out = p.out;
         sp.state = static_cast<float *>(s->state.ptr);
         sp.order = static_cast<const uint32_t *>(s->order.ptr);
@@ -238,6 +272,7 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
         HIP_TRY(launch_skeleton_serial(sp, st));
     } else {
         SkeletonParams fp;
+        fp.morph = morph_state;
         fp.poses = p.poses; fp.out = p.out;
         fp.local_offset = static_cast<const float *>(s->local_offset.ptr);
         fp.neg_rest = static_cast<const float *>(s->neg_rest.ptr);
@@ -249,8 +284,8 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
     if (!(flags & MMDX_OUT_ON_DEVICE)) {
         if (out_bytes) HIP_TRY(hipMemcpyAsync(out_palettes, p.out, out_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-    } else if (!(flags & MMDX_POSES_ON_DEVICE)) {
-        HIP_TRY(hipStreamSynchronize(st));   // borrowed host poses must be consumed before returning
+    } else if (!(flags & MMDX_POSES_ON_DEVICE) || borrowed_rates) {
+        HIP_TRY(hipStreamSynchronize(st));   // borrowed host poses / rates must be consumed before returning
     }
     return MMDX_OK;
 }

@@ -93,15 +93,16 @@ struct Mat4 {
 
 // local_matrix_ of one bone before the parent product (Poser::UpdateBoneTransform,
 // L/motion/poser_impl.inl:142-162, with no bone morph: morph_rotation_ = identity, morph_translation_ = 0).
-__device__ __forceinline__ Mat4 local_matrix(const float4 t, const float4 r, const float4 off) {
-    // total_rotation_ = identity * rotation_   (Quaternion::operator*, L/util/math_impl.inl:510-517)
-    const float mi = 0.f, mj = 0.f, mk = 0.f, me = 1.f;
+__device__ __forceinline__ Mat4 local_matrix(const float4 t, const float4 r, const float4 off, const float mtx,
+                                             const float mty, const float mtz, const float mi, const float mj,
+                                             const float mk, const float me) {
+    // total_rotation_ = morph_rotation_ * rotation_   (Quaternion::operator*, L/util/math_impl.inl:510-517)
     const float i = (me * r.x + mi * r.w + mj * r.z) - mk * r.y;
     const float j = (me * r.y + mj * r.w + mk * r.x) - mi * r.z;
     const float k = (me * r.z + mi * r.y + mk * r.w) - mj * r.x;
     const float e = me * r.w - (mi * r.x + mj * r.y + mk * r.z);
     // total_translation_ = morph_translation_ + translation_
-    const float tx = 0.f + t.x, ty = 0.f + t.y, tz = 0.f + t.z;
+    const float tx = mtx + t.x, ty = mty + t.y, tz = mtz + t.z;
     // Quaternion::ToRotateMatrix, L/util/math_impl.inl:540-563
     const float ii = i * i, jj = j * j, kk = k * k, ij = i * j, jk = j * k, ki = i * k, ie = i * e, je = j * e,
                 ke = k * e;
@@ -148,7 +149,14 @@ __global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const Skeleton
     }
     for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t b = p.chain[c];
-        const Mat4 L = local_matrix(pose[2 * size_t(b)], pose[2 * size_t(b) + 1], off[b]);
+        float mt[3] = {0.f, 0.f, 0.f}, mq[4] = {0.f, 0.f, 0.f, 1.f};      // no bone morph: zero / identity
+        if (p.morph) {
+            const float *ms = p.morph + size_t(b) * kMorphStateFloats * p.ni + i;
+            mt[0] = ms[0]; mt[1] = ms[size_t(p.ni)]; mt[2] = ms[2 * size_t(p.ni)];
+            mq[0] = ms[3 * size_t(p.ni)]; mq[1] = ms[4 * size_t(p.ni)]; mq[2] = ms[5 * size_t(p.ni)]; mq[3] = ms[6 * size_t(p.ni)];
+        }
+        const Mat4 L = local_matrix(pose[2 * size_t(b)], pose[2 * size_t(b) + 1], off[b], mt[0], mt[1], mt[2], mq[0],
+                                    mq[1], mq[2], mq[3]);
         M = have ? mul(L, M) : L;
         have = true;
     }
@@ -333,11 +341,22 @@ __device__ void place_at(const S &st, const BoneRec &rec, uint32_t self, int32_t
 
 // UpdateBoneTransform up to (not including) the IK solve, poser_impl.inl:142-166.  `ap` = state index of
 // the append parent (read only when the bone appends).
+struct MorphXf {                                  // morph_translation_, morph_rotation_ of one bone
+    float tx, ty, tz;
+    Quat q;
+};
+__device__ __forceinline__ MorphXf morph_of(const SerialParams &p, uint32_t bone, uint32_t inst) {
+    if (!p.morph) return {0.f, 0.f, 0.f, q_identity()};
+    const float *ms = p.morph + size_t(bone) * kMorphStateFloats * p.ni + inst;
+    const size_t n = p.ni;
+    return {ms[0], ms[n], ms[2 * n], {ms[3 * n], ms[4 * n], ms[5 * n], ms[6 * n]}};
+}
+
 template <class S>
-__device__ void transform_at(const S &st, const BoneRec &rec, const float4 t, const float4 r, uint32_t self,
-                             int32_t parent, uint32_t ap) {
-    Quat total = q_mul(q_identity(), {r.x, r.y, r.z, r.w});
-    float tx = 0.f + t.x, ty = 0.f + t.y, tz = 0.f + t.z;
+__device__ void transform_at(const S &st, const BoneRec &rec, const MorphXf mx, const float4 t, const float4 r,
+                             uint32_t self, int32_t parent, uint32_t ap) {
+    Quat total = q_mul(mx.q, {r.x, r.y, r.z, r.w});
+    float tx = mx.tx + t.x, ty = mx.ty + t.y, tz = mx.tz + t.z;
     if (rec.bits & (kBoneAppendRot | kBoneAppendTr)) {
         // the reference assigns total_rotation_ / total_translation_ before reading the append parent's,
         // which matters when a bone names itself: keep that order
@@ -362,26 +381,30 @@ __device__ void transform_at(const S &st, const BoneRec &rec, const float4 t, co
     place_at(st, rec, self, parent);
 }
 
-__device__ __forceinline__ void transform_bone(const State &st, const SerialParams &p, const float4 *pose, uint32_t b) {
+__device__ __forceinline__ void transform_bone(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst,
+                                               uint32_t b) {
     const BoneRec rec = p.bones[b];
-    transform_at(st, rec, pose[2 * size_t(b)], pose[2 * size_t(b) + 1], b, rec.parent, uint32_t(rec.append_parent));
+    transform_at(st, rec, morph_of(p, b, inst), pose[2 * size_t(b)], pose[2 * size_t(b) + 1], b, rec.parent,
+                 uint32_t(rec.append_parent));
 }
 
 // The CCD loop of UpdateBoneTransform, poser_impl.inl:196-309, over a state `st` in which link j lives at
 // index lidx(j), the target at tidx, their parents at lpar(j) / tpar (< 0 = none).  Two instantiations:
 // directly on the HBM scratch (indices = bone ids), or on an LDS window holding just the chain (fast path).
 template <class S, class LIdx, class LPar>
-__device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, const IkRec &ik, const LinkRec *links,
-                    const V3 ik_pos, LIdx lidx, LPar lpar, uint32_t tidx, int32_t tpar) {
+__device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint32_t inst, const IkRec &ik,
+                    const LinkRec *links, const V3 ik_pos, LIdx lidx, LPar lpar, uint32_t tidx, int32_t tpar) {
     const BoneRec trec = p.bones[ik.target];
     const float4 tt = pose[2 * size_t(ik.target)], tr = pose[2 * size_t(ik.target) + 1];
+    const MorphXf tmx = morph_of(p, ik.target, inst);
     for (uint32_t i = 0; i < ik.nlinks; ++i) st.set_quat(lidx(i), kStIkRot, q_identity());
     for (uint32_t i = 0; i < ik.nlinks; ++i) {
         const uint32_t j = ik.nlinks - i - 1, lb = links[j].bone;
         const BoneRec rec = p.bones[lb];
-        transform_at(st, rec, pose[2 * size_t(lb)], pose[2 * size_t(lb) + 1], lidx(j), lpar(j), uint32_t(rec.append_parent));
+        transform_at(st, rec, morph_of(p, lb, inst), pose[2 * size_t(lb)], pose[2 * size_t(lb) + 1], lidx(j), lpar(j),
+                     uint32_t(rec.append_parent));
     }
-    transform_at(st, trec, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
+    transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
     V3 tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
     V3 err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
     if (v_dot(err, err) < 1e-7f) return;
@@ -441,7 +464,7 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, cons
                 st.set_quat(bs, kStTotalRot, q_mul(st.quat(bs, kStIkRot), st.quat(bs, kStPreIkRot)));
                 place_at(st, p.bones[links[jj].bone], bs, lpar(jj));
             }
-            transform_at(st, trec, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
+            transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
             tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
         }
         err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
@@ -453,7 +476,7 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, cons
 // the first link, no append bones inside; IkRec::fast, decided on the host) are solved on an LDS window:
 // their few bones' state is copied in, the up-to-256-iteration loop runs at LDS latency instead of paying
 // HBM-scratch round trips for every dependent access, and the result is copied back.  Same arithmetic.
-__device__ void solve_ik(const State &st, const SerialParams &p, const float4 *pose, uint32_t b,
+__device__ void solve_ik(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst, uint32_t b,
                          __attribute__((address_space(3))) float *lds_lane) {
     const IkRec ik = p.iks[p.bones[b].ik];
     const LinkRec *links = p.links + ik.link0;
@@ -471,13 +494,45 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
         for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, true);
         copy(n, ik.target, true);
         if (outside >= 0) copy(n + 1, uint32_t(outside), true);
-        ccd(cs, p, pose, ik, links, ik_pos, [](uint32_t j) { return j; },
+        ccd(cs, p, pose, inst, ik, links, ik_pos, [](uint32_t j) { return j; },
             [&](uint32_t j) { return j + 1 < n ? int32_t(j + 1) : (outside >= 0 ? int32_t(n + 1) : -1); }, n, 0);
         for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, false);
         copy(n, ik.target, false);
     } else {
-        ccd(st, p, pose, ik, links, ik_pos, [&](uint32_t j) { return links[j].bone; },
+        ccd(st, p, pose, inst, ik, links, ik_pos, [&](uint32_t j) { return links[j].bone; },
             [&](uint32_t j) { return p.bones[links[j].bone].parent; }, ik.target, p.bones[ik.target].parent);
+    }
+}
+
+// Bone morphs -> per-bone morph_translation_ / morph_rotation_ (Poser::UpdateMorphTransform, MORPH_TYPE_BONE,
+// L/motion/poser_impl.inl:347-354, after the reset of :369-370).  One thread per instance walks the
+// applications in the reference's order (the quaternion products of one bone do not commute); rates below
+// 1e-7 skip at every group level like the vertex morphs.  Output [bone][7][instance].
+__global__ __launch_bounds__(kSerialThreads) void bone_morph_kernel(const BoneMorphParams p) {
+    const uint32_t inst = blockIdx.x * kSerialThreads + threadIdx.x;
+    if (inst >= p.ni) return;
+    float *out = p.out + inst;
+    const size_t n = p.ni;
+    for (uint32_t b = 0; b < p.nb; ++b) {
+        float *o = out + size_t(b) * kMorphStateFloats * n;
+        o[0] = 0.f; o[n] = 0.f; o[2 * n] = 0.f;
+        o[3 * n] = 0.f; o[4 * n] = 0.f; o[5 * n] = 0.f; o[6 * n] = 1.f;
+    }
+    const float *rates = p.rates + (p.shared ? 0 : size_t(inst) * p.nm);
+    for (uint32_t a = 0; a < p.napps; ++a) {
+        const BoneMorphApp app = p.apps[a];
+        float r = rates[app.top];
+        bool skip = r < 1e-7f;
+        for (uint32_t c = 0; !skip && c < app.chain_len; ++c) {
+            r = p.chain[app.chain_off + c] * r;
+            skip = r < 1e-7f;
+        }
+        if (skip) continue;
+        float *o = out + size_t(app.bone) * kMorphStateFloats * n;
+        o[0] = o[0] + app.tr[0] * r; o[n] = o[n] + app.tr[1] * r; o[2 * n] = o[2 * n] + app.tr[2] * r;
+        const Quat cur = {o[3 * n], o[4 * n], o[5 * n], o[6 * n]};
+        const Quat q = q_mul(cur, q_slerp_from_identity({app.rot[0], app.rot[1], app.rot[2], app.rot[3]}, r));
+        o[3 * n] = q.i; o[4 * n] = q.j; o[5 * n] = q.k; o[6 * n] = q.e;
     }
 }
 
@@ -501,8 +556,8 @@ __global__ __launch_bounds__(kSerialThreads) void skeleton_serial_kernel(const S
         const uint32_t s0 = pass ? p.n_pre : 0, s1 = pass ? p.nb : p.n_pre;
         for (uint32_t s = s0; s < s1; ++s) {
             const uint32_t b = p.order[s];
-            transform_bone(st, p, pose, b);
-            if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, b, lds_lane);
+            transform_bone(st, p, pose, inst, b);
+            if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, inst, b, lds_lane);
         }
         for (uint32_t s = s0; s < s1; ++s) {               // UpdateBoneSkinningMatrix of this list
             const uint32_t b = p.order[s];
@@ -535,6 +590,13 @@ hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(skeleton_fk_kernel, dim3(uint32_t((n + kRigThreads - 1) / kRigThreads)),
                        dim3(kRigThreads), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream) {
+    if (p.ni == 0 || p.nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(bone_morph_kernel, dim3((p.ni + kSerialThreads - 1) / kSerialThreads), dim3(kSerialThreads), 0,
+                       stream, p);
     return hipGetLastError();
 }
 

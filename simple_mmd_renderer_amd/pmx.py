@@ -39,6 +39,7 @@ class PmxWriteOptions:
     bone_names: Optional[List[str]] = None
     morph_names: Optional[List[str]] = None
     rig: Optional[tuple] = None        # synth.make_ik_rig(...) output: levels, flag bits, append and IK records
+    morph_rotation: Optional[np.ndarray] = None   # f32 [E,4]: rotation of bone-morph entries (default identity)
     model_name: str = "合成モデル synthetic"
 
 
@@ -214,7 +215,8 @@ def write_pmx(m: FlatModel, opt: Optional[PmxWriteOptions] = None) -> bytes:
             elif t == 1:
                 index(idx, w_vertex, unsigned=True); out.extend(np.asarray(v, "<f4").tobytes())
             elif t == 2:
-                index(idx, w_bone); out.extend(np.asarray(v, "<f4").tobytes()); f(0, 0, 0, 1)
+                index(idx, w_bone); out.extend(np.asarray(v, "<f4").tobytes())
+                f(*(opt.morph_rotation[e] if opt.morph_rotation is not None else (0, 0, 0, 1)))
             elif 3 <= t <= 7:
                 index(idx, w_vertex, unsigned=True); out.extend(np.asarray(v, "<f4").tobytes()); f(0.0)
             elif t == 8:
@@ -253,12 +255,16 @@ class PmxModel:
     append_parent: Optional[np.ndarray] = None
     append_ratio: Optional[np.ndarray] = None
     ik: Optional[dict] = None          # target, loop, angle, link_off, link_bone, link_limited, link_lo, link_hi
+    morph_rotation: Optional[np.ndarray] = None   # f32 [E,4], identity except for bone-morph entries
 
     def skeleton(self):
         """The device bone solver for this model's rig (vmd.Skeleton)."""
         from .vmd import Skeleton
-        return Skeleton(self.flat.bone_pos, self.flat.bone_parent, self.bone_transform_level, self.bone_flags,
-                        self.append_parent, self.append_ratio, self.ik)
+        f = self.flat
+        morphs = dict(type=f.morph_type, offset=f.morph_off, index=f.morph_index, value=f.morph_value,
+                      rotation=self.morph_rotation) if f.nm else None
+        return Skeleton(f.bone_pos, f.bone_parent, self.bone_transform_level, self.bone_flags,
+                        self.append_parent, self.append_ratio, self.ik, morphs)
 
 
 class PmxInfo(C.Structure):
@@ -331,6 +337,7 @@ def load_pmx(source) -> PmxModel:
                   link_off=link_off, link_bone=vp(sd.ik_link_bone, nl, i32), link_limited=vp(sd.ik_link_limited, nl, np.uint8),
                   link_lo=vp(sd.ik_link_lo, nl * 3, f32).reshape(nl, 3), link_hi=vp(sd.ik_link_hi, nl * 3, f32).reshape(nl, 3))
         append_parent, append_ratio = vp(sd.append_parent, nb, i32), vp(sd.append_ratio, nb, f32)
+        morph_rotation = vp(sd.morph_rotation, ne * 4, f32).reshape(ne, 4)
 
         def name(kind, i):
             buf = C.create_string_buffer(1024)
@@ -347,6 +354,6 @@ def load_pmx(source) -> PmxModel:
             bone_flags=_arr(a.bone_flags, nb, np.uint16),
             name=name(0, 0), bone_names=[name(1, i) for i in range(nb)],
             morph_names=[name(2, i) for i in range(nm)],
-            append_parent=append_parent, append_ratio=append_ratio, ik=ik)
+            append_parent=append_parent, append_ratio=append_ratio, ik=ik, morph_rotation=morph_rotation)
     finally:
         lib.mmdx_pmx_destroy(h)

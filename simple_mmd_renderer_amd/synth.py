@@ -331,3 +331,38 @@ def make_ik_rig(nb: int, seed: int, n_ik: int = 4, n_append: int = 4, post_physi
               link_limited=np.asarray(link_limited, np.uint8).reshape(-1),
               link_lo=np.asarray(lo, np.float32).reshape(-1, 3), link_hi=np.asarray(hi, np.float32).reshape(-1, 3))
     return rest, parent, level, flags, append_parent, append_ratio, ik
+
+
+def make_bone_morphs(nb: int, seed: int, n_bone: int = 5, n_group: int = 3, n_other: int = 2):
+    """A morph table with bone morphs (translation + rotation, several bones each, a bone hit by several morphs),
+    group morphs over them (depth 2, a bone morph reached directly and through a group) and a few vertex / uv
+    morphs that the bone solve must ignore.  dict(type, offset, index, value, rotation)."""
+    rng = np.random.RandomState(seed)
+    types, off, index, value, rot = [], [0], [], [], []
+    nm = n_other + n_bone + n_group
+    for _ in range(n_other):                                   # ignored types first (indices must still line up)
+        types.append(int(rng.choice([1, 3, 8])))
+        for _ in range(rng.randint(0, 3)):
+            index.append(0); value.append([0.1, 0.2, 0.3]); rot.append([0, 0, 0, 1])
+        off.append(len(index))
+    for _ in range(n_bone):
+        types.append(2)
+        for _ in range(rng.randint(1, 4)):
+            q = rng.normal(size=4)
+            q = q / np.linalg.norm(q) * (1.0 if rng.uniform() < 0.8 else 0.9)
+            if rng.uniform() < 0.15:
+                q = np.array([0, 0, 0, 1.0])                   # pure translation morph
+            index.append(int(rng.randint(0, min(nb, 6)) if rng.uniform() < 0.5 else rng.randint(0, nb)))
+            value.append(rng.uniform(-0.5, 0.5, 3)); rot.append(q)
+        off.append(len(index))
+    for g in range(n_group):
+        types.append(0)
+        lo = n_other if g < n_group - 1 else n_other + n_bone    # the last group also nests the other groups
+        for _ in range(rng.randint(1, 4)):
+            index.append(int(rng.randint(lo, n_other + n_bone + g) if g == n_group - 1 and g > 0
+                             else rng.randint(n_other, n_other + n_bone)))
+            value.append([float(rng.choice([0.5, 1.0, 1e-4, 2.0])), 0, 0]); rot.append([0, 0, 0, 1])
+        off.append(len(index))
+    assert len(types) == nm
+    return dict(type=np.asarray(types, np.int32), offset=np.asarray(off, np.uint32), index=np.asarray(index, np.uint32),
+                value=np.asarray(value, np.float32).reshape(-1, 3), rotation=np.asarray(rot, np.float32).reshape(-1, 4))

@@ -157,7 +157,7 @@ class MorphMotion:
 
 
 FRAMES_ON_DEVICE = 1 << 0
-POSES_ON_DEVICE = 1 << 1
+POSES_ON_DEVICE = 1 << 4
 POSE_FLOATS = 8
 
 
@@ -206,14 +206,17 @@ class SkeletonDesc(C.Structure):
                 ("append_parent", C.c_void_p), ("append_ratio", C.c_void_p),
                 ("ik_target", C.c_void_p), ("ik_loop_count", C.c_void_p), ("ik_angle_limit", C.c_void_p),
                 ("ik_link_offset", C.c_void_p), ("ik_link_bone", C.c_void_p), ("ik_link_limited", C.c_void_p),
-                ("ik_link_lo", C.c_void_p), ("ik_link_hi", C.c_void_p)]
+                ("ik_link_lo", C.c_void_p), ("ik_link_hi", C.c_void_p),
+                ("n_morphs", C.c_uint32), ("reserved0", C.c_uint32), ("morph_type", C.c_void_p),
+                ("morph_offset", C.c_void_p), ("morph_index", C.c_void_p), ("morph_value", C.c_void_p),
+                ("morph_rotation", C.c_void_p)]
 
 
 class SkeletonInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_bones", C.c_uint32), ("n_pre_physics", C.c_uint32),
                 ("n_post_physics", C.c_uint32), ("max_chain", C.c_uint32), ("solver", C.c_uint32),
                 ("n_ik_bones", C.c_uint32), ("n_ik_links", C.c_uint32), ("n_append_bones", C.c_uint32),
-                ("reserved0", C.c_uint32)]
+                ("n_bone_morph_entries", C.c_uint32)]
 
 
 SOLVER_PARALLEL_FK, SOLVER_SERIAL = 0, 1
@@ -226,7 +229,9 @@ class Skeleton:
     synth.make_ik_rig / the PMX loader; None for a rig without IK."""
 
     def __init__(self, rest_position, parent, transform_level=None, flags=None, append_parent=None,
-                 append_ratio=None, ik=None):
+                 append_ratio=None, ik=None, morphs=None):
+        """morphs = dict(type i32[NM], offset u32[NM+1], index u32[E], value f32[E,3], rotation f32[E,4] or None):
+        the model's morph table; its group and bone morphs feed mmdx_skeleton_solve_morphed."""
         rest = np.ascontiguousarray(rest_position, np.float32).reshape(-1, 3)
         nb = rest.shape[0]
 
@@ -243,9 +248,17 @@ class Skeleton:
                      arr(ik["link_lo"], np.float32), arr(ik["link_hi"], np.float32)]
         else:
             keep += [None] * 8
-        d = SkeletonDesc(C.sizeof(SkeletonDesc), nb, *[a.ctypes.data if a is not None and a.size else
-                                                        (a.ctypes.data if a is not None else None) for a in keep])
-        self._keep = keep
+        nm = 0
+        if morphs is not None:
+            nm = int(np.asarray(morphs["type"]).size)
+            mk = [arr(morphs["type"], np.int32, nm), arr(morphs["offset"], np.uint32, nm + 1), arr(morphs["index"], np.uint32),
+                  arr(morphs["value"], np.float32), arr(morphs.get("rotation"), np.float32)]
+        else:
+            mk = [None] * 5
+        ptr = lambda a: a.ctypes.data if a is not None else None          # noqa: E731
+        d = SkeletonDesc(C.sizeof(SkeletonDesc), nb, *[ptr(a) for a in keep], nm, 0, *[ptr(a) for a in mk])
+        self._keep = keep + mk
+        self.nm = nm
         self.h = C.c_void_p()
         api.check(api.lib().mmdx_skeleton_create(C.byref(d), C.byref(self.h)))
         info = SkeletonInfo()
@@ -254,18 +267,28 @@ class Skeleton:
         self.info = {k: getattr(info, k) for k, _ in SkeletonInfo._fields_}
         self.nb = nb
 
-    def solve(self, poses, model=None) -> np.ndarray:
-        """Host convenience: poses f32 [NI, NB, 8] -> palettes f32 [NI, NB, 16]."""
+    def solve(self, poses, model=None, morph_weights=None) -> np.ndarray:
+        """Host convenience: poses f32 [NI, NB, 8] (+ morph rates [NI, NM] or shared [NM]) -> palettes
+        f32 [NI, NB, 16]."""
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, self.nb, POSE_FLOATS)
         out = np.empty((p.shape[0], self.nb, 16), np.float32)
-        api.check(api.lib().mmdx_skeleton_solve(self.h, model.h if model is not None else None, p.shape[0],
-                                                p.ctypes.data, 0, out.ctypes.data))
+        if morph_weights is None:
+            api.check(api.lib().mmdx_skeleton_solve(self.h, model.h if model is not None else None, p.shape[0],
+                                                    p.ctypes.data, 0, out.ctypes.data))
+        else:
+            w = np.ascontiguousarray(morph_weights, np.float32)
+            flags = api.WEIGHTS_SHARED if w.ndim == 1 else 0
+            assert w.shape[-1] == self.nm and (w.ndim == 1 or w.shape[0] == p.shape[0])
+            api.check(api.lib().mmdx_skeleton_solve_morphed(self.h, model.h if model is not None else None, p.shape[0],
+                                                            p.ctypes.data, w.ctypes.data, flags, out.ctypes.data))
         return out
 
-    def solve_device(self, n_instances: int, poses_ptr, out_ptr, model=None) -> None:
-        """poses and palettes resident in HBM; asynchronous on the model's stream."""
-        api.check(api.lib().mmdx_skeleton_solve(self.h, model.h if model is not None else None, n_instances,
-                                                poses_ptr, POSES_ON_DEVICE | api.OUT_ON_DEVICE, out_ptr))
+    def solve_device(self, n_instances: int, poses_ptr, out_ptr, model=None, weights_ptr=None, shared=False) -> None:
+        """poses, palettes (and morph rates) resident in HBM; asynchronous on the model's stream."""
+        flags = POSES_ON_DEVICE | api.OUT_ON_DEVICE | (api.WEIGHTS_ON_DEVICE if weights_ptr else 0) | \
+            (api.WEIGHTS_SHARED if shared else 0)
+        api.check(api.lib().mmdx_skeleton_solve_morphed(self.h, model.h if model is not None else None, n_instances,
+                                                        poses_ptr, weights_ptr, flags, out_ptr))
 
     def close(self):
         if getattr(self, "h", None):

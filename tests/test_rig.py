@@ -198,6 +198,64 @@ def test_oracle_full_bone_solve_vs_reference(oracle, nb, seed, n_ik, n_app):
     assert moved == 4                                        # the IK / append machinery really ran
 
 
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
+@pytest.mark.parametrize("nb,seed,n_ik,n_app", [(30, 0, 0, 0), (44, 1, 3, 4), (80, 2, 5, 6)])
+def test_oracle_bone_morphs_vs_reference(oracle, nb, seed, n_ik, n_app):
+    """Bone morphs (translation + SLerp'ed rotation, through groups) feeding the bone solve."""
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, seed, n_ik=n_ik, n_append=n_app)
+    morphs = synth.make_bone_morphs(nb, 70 + seed)
+    ref = Reference.skeleton(rest, parent, level, flags, ap, ar, ik, morphs)
+    rng = np.random.RandomState(seed)
+    for i, poses in enumerate(random_poses(4, nb, 400 + seed)):
+        rates = rng.choice([0, 5e-8, 0.3, 1.0, 1.7, -0.5], morphs["type"].size).astype(np.float32)
+        got = oracle.bone_solve_full(rest, parent, poses, level, flags, ap, ar, ik, morphs, rates)
+        gu.assert_bits_equal(got, ref.solve(poses, rates), f"palette {i}")
+    ref.close()
+
+
+def test_bone_morph_table_host_side():
+    rest, parent, level, flags = synth.make_skeleton(20, 3)
+    morphs = synth.make_bone_morphs(20, 9)
+    sk = vmd.Skeleton(rest, parent, level, flags, morphs=morphs)
+    assert sk.info["n_bone_morph_entries"] > 0 and sk.info["solver"] == vmd.SOLVER_PARALLEL_FK
+    bad = dict(morphs, index=morphs["index"].copy())
+    e = int(morphs["offset"][np.flatnonzero(morphs["type"] == 2)[0]])
+    bad["index"][e] = 20                                     # bone index out of range
+    with pytest.raises(api.MmdxError) as ex:
+        vmd.Skeleton(rest, parent, level, flags, morphs=bad)
+    assert ex.value.status == 2
+    g = int(np.flatnonzero(morphs["type"] == 0)[0])
+    cyc = dict(morphs, index=morphs["index"].copy())
+    cyc["index"][int(morphs["offset"][g])] = g               # a group that contains itself
+    with pytest.raises(api.MmdxError) as ex:
+        vmd.Skeleton(rest, parent, level, flags, morphs=cyc)
+    assert ex.value.status == 6 and "contains itself" in str(ex.value)
+
+
+def test_pmx_bone_morph_rotation_round_trip():
+    m = synth.make_model(60, 12, 0, 1, seed=3)
+    morphs = synth.make_bone_morphs(12, 4)
+    m.morph_type, m.morph_off = morphs["type"], morphs["offset"]
+    m.morph_index, m.morph_value = morphs["index"], morphs["value"]
+    pm = pmx.load_pmx(pmx.write_pmx(m, pmx.PmxWriteOptions(morph_rotation=morphs["rotation"], bone_flag_variety=False)))
+    is_bone = np.repeat(morphs["type"] == 2, np.diff(morphs["offset"].astype(np.int64)))
+    assert np.array_equal(pm.morph_rotation[is_bone], morphs["rotation"][is_bone])
+    assert np.all(pm.morph_rotation[~is_bone] == np.array([0, 0, 0, 1], np.float32))
+    assert pm.skeleton().info["n_bone_morph_entries"] > 0
+
+
+def test_golden_bone_morph_rig_oracle(oracle):
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "rig_morph_expect.npz"))
+    for tag in ("fk", "ik"):
+        ik = {k[len(tag) + 4:]: z[k] for k in z.files if k.startswith(tag + "_ik_")} or None
+        morphs = {k[len(tag) + 7:]: z[k] for k in z.files if k.startswith(tag + "_morph_")}
+        for i in range(z[tag + "_poses"].shape[0]):
+            got = oracle.bone_solve_full(z[tag + "_rest"], z[tag + "_parent"], z[tag + "_poses"][i], z[tag + "_level"],
+                                         z[tag + "_flags"], z[tag + "_append_parent"], z[tag + "_append_ratio"], ik,
+                                         morphs, z[tag + "_rates"][i])
+            gu.assert_bits_equal(got, z[tag + "_expect_palettes"][i], f"{tag} palette {i}")
+
+
 def test_golden_ik_rig_oracle(oracle):
     """tests/golden/rig_ik_expect.npz: libmmd's palettes for rigs with IK chains and append bones."""
     z = np.load(os.path.join(gu.GOLDEN_DIR, "rig_ik_expect.npz"))
@@ -395,3 +453,47 @@ def test_gpu_pmx_rig_to_palettes(oracle):
         want = oracle.bone_solve_full(pm.flat.bone_pos, pm.flat.bone_parent, poses[i], pm.bone_transform_level,
                                       pm.bone_flags, pm.append_parent, pm.append_ratio, pm.ik)
         gu.assert_bits_equal(got[i], want, f"palette of instance {i}")
+
+
+def _golden_morph_case(z, tag):
+    ik = {k[len(tag) + 4:]: z[k] for k in z.files if k.startswith(tag + "_ik_")} or None
+    morphs = {k[len(tag) + 7:]: z[k] for k in z.files if k.startswith(tag + "_morph_")}
+    return ik, morphs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["fk", "ik"])
+def test_gpu_golden_bone_morph_rig(tag):
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "rig_morph_expect.npz"))
+    ik, morphs = _golden_morph_case(z, tag)
+    sk = vmd.Skeleton(z[tag + "_rest"], z[tag + "_parent"], z[tag + "_level"], z[tag + "_flags"],
+                      z[tag + "_append_parent"], z[tag + "_append_ratio"], ik, morphs)
+    assert sk.info["solver"] == (vmd.SOLVER_SERIAL if tag == "ik" else vmd.SOLVER_PARALLEL_FK)
+    got = sk.solve(z[tag + "_poses"], morph_weights=z[tag + "_rates"])
+    gu.assert_bits_equal(got, z[tag + "_expect_palettes"], "palettes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,seed,n_ik,n_app", [(30, 0, 0, 0), (44, 1, 3, 4), (150, 2, 6, 8)])
+def test_gpu_bone_morphs_vs_oracle(oracle, nb, seed, n_ik, n_app):
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, seed, n_ik=n_ik, n_append=n_app)
+    morphs = synth.make_bone_morphs(nb, 90 + seed)
+    nm = morphs["type"].size
+    sk = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik, morphs)
+    poses = random_poses(70, nb, 500 + seed)
+    rng = np.random.RandomState(seed)
+    rates = rng.choice([0, 5e-8, 0.3, 1.0, 1.7, -0.5], (70, nm)).astype(np.float32)
+    got = sk.solve(poses, morph_weights=rates)
+    shared = sk.solve(poses, morph_weights=rates[3])
+    plain = sk.solve(poses)
+    for i in range(70):
+        gu.assert_bits_equal(got[i], oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, ik, morphs, rates[i]),
+                             f"palette of instance {i}")
+        gu.assert_bits_equal(plain[i], oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, ik), f"plain {i}")
+    gu.assert_bits_equal(shared[9], oracle.bone_solve_full(rest, parent, poses[9], level, flags, ap, ar, ik, morphs, rates[3]),
+                         "shared weights")
+    # device-resident operands
+    d_pose, d_w, d_out = DeviceBuffer.from_numpy(poses), DeviceBuffer.from_numpy(rates), DeviceBuffer(70 * nb * 64)
+    sk.solve_device(70, d_pose.ptr, d_out.ptr, None, d_w.ptr)
+    api.check(api.lib().mmdx_device_synchronize())
+    gu.assert_bits_equal(d_out.download((70, nb, 16), np.float32), got, "device-resident call")
