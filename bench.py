@@ -95,7 +95,7 @@ def main():
     # Output arrays through the engine's placement-aware allocator: on MI355X the store rate of the crowd
     # pattern depends on where the driver puts the arrays (bimodal); set-up work,
     # outside the timed region.  --plain-alloc takes whatever hipMalloc hands out first.
-    d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else 24)
+    d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else 64)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
 
     def step():

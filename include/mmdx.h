@@ -229,9 +229,10 @@ MMDX_API mmdx_status mmdx_bench_store_pattern(void *out_a_device, void *out_b_de
  * the driver places the arrays (same virtual addresses, different physical backing: ~0.97 or ~0.75 of the
  * linear-fill rate, stable for the life of the allocation; tools/alloc_probe.py, alloc_kernel_probe.py),
  * and the deform kernel follows it.  This helper allocates, times the store-only replay of the pattern
- * against a linear fill, and retries up to `max_tries` times (rejected placements stay allocated until it
- * returns, so each try lands elsewhere), keeping the best placement seen.  max_tries <= 1: plain
- * allocation.  Free both arrays with mmdx_device_free(). */
+ * against a linear fill, and retries up to `max_tries` times (about one placement in seven is the fast
+ * one; ~5 ms per try), keeping the best placement seen, then waits until the driver's background wipe of
+ * the freed candidates no longer shows.  max_tries <= 1: plain allocation.  Free both arrays with
+ * mmdx_device_free(). */
 typedef struct mmdx_placement_info {
     uint32_t struct_size;
     uint32_t tries;          /* allocations made                                                        */

@@ -779,11 +779,22 @@ mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_
         if (e == hipSuccess) e = time_store_pattern(c.a, c.b, nv, n_instances, bpva, bpvb, 5, &ms);
         if (e != hipSuccess) { release(c); st = hip_fail(e, "probing a placement of the crowd output arrays"); break; }
         c.gbs = float(double(bytes_a + bytes_b) / (ms * 1e-3) / 1e9);
-        if (c.gbs > best.gbs) { if (best.a) parked.push_back(best); best = c; } else parked.push_back(c);
+        if (env_int("MMDX_PLACEMENT_LOG", 0))
+            std::fprintf(stderr, "mmdx placement try %u: a=%p b=%p store %.0f GB/s (fill %.0f)\n", tries, c.a, c.b, c.gbs, fill_gbs);
+        // measured (tools/shop_probe.py): about one placement in seven is fast either way; freeing a rejected
+        // candidate at once needs a few tries less on average than keeping it parked, and no extra memory
+        const bool park = env_int("MMDX_PLACEMENT_PARK", 0) != 0;
+        if (c.gbs > best.gbs) {
+            if (best.a) { if (park) parked.push_back(best); else release(best); }
+            best = c;
+        } else if (park) {
+            parked.push_back(c);
+        } else {
+            release(c);
+        }
         if (best.gbs >= 0.92f * fill_gbs) break;     // the fast mode sits at 0.96-0.99 of the fill rate, the slow ones at 0.72-0.8
     }
-    // rejected placements stayed allocated until here, so that every new try had to land somewhere else
-    const bool freed_any = !parked.empty();
+    const bool freed_any = tries > 1;
     for (Cand &c : parked) release(c);
     if (st != MMDX_OK) { release(best); return st; }
     // The driver wipes freed VRAM in the background (gigabytes per rejected try), which steals HBM bandwidth
