@@ -279,6 +279,13 @@ enum { MMDX_PMX_NAME_MODEL = 0, MMDX_PMX_NAME_BONE = 1, MMDX_PMX_NAME_MORPH = 2,
 
 MMDX_API mmdx_status mmdx_pmx_parse(const void *data, size_t size, mmdx_pmx_t *out_pmx);
 MMDX_API mmdx_status mmdx_pmx_load_file(const char *path, mmdx_pmx_t *out_pmx);
+/* PMD 1.0, the older format: replaces PmdReader::ReadModel (L/reader/pmd_reader_impl.inl:16-566) for the same
+ * fields and yields the same kind of handle, so every mmdx_pmx_* accessor below serves it (incl. the rig: PMD
+ * bone types and IK list are converted to flag words, append and IK tables exactly as libmmd converts them;
+ * a second IK record of one bone appends a bone, so n_bones can exceed the file's count).  All vertices
+ * are BDEF2 with weight byte * 0.01f; morph indices are resolved through the base morph. */
+MMDX_API mmdx_status mmdx_pmd_parse(const void *data, size_t size, mmdx_pmx_t *out_pmx);
+MMDX_API mmdx_status mmdx_pmd_load_file(const char *path, mmdx_pmx_t *out_pmx);
 MMDX_API void mmdx_pmx_destroy(mmdx_pmx_t pmx);
 MMDX_API mmdx_status mmdx_pmx_get_info(mmdx_pmx_t pmx, mmdx_pmx_info *info);
 /* Fills `desc` with pointers into `pmx` (valid until mmdx_pmx_destroy) and MMDX_CREATE_NORMALIZE,

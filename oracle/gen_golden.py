@@ -396,6 +396,38 @@ def main():
     np.savez_compressed(os.path.join(OUT, "rig_morph_expect.npz"), **gm)
     print(f"{'rig_morph_expect.npz':28s} FK + IK rigs with bone morphs, 8 poses each")
 
+    # PMD fixture: a small PMD 1.0 file (all bone types, two IK records on one bone, base morph) and what
+    # libmmd's PmdReader + Poser make of it: deformed vertices for given rates / palettes, and the palettes its
+    # bone solve produces for given local poses.
+    from simple_mmd_renderer_amd import pmd as pmdmod
+    pdata, _, _ = pmdmod.make_rigged_pmd(7, nv=180, nb=16, extended=True)
+    ppath = os.path.join(OUT, "pmd_small.pmd")
+    open(ppath, "wb").write(pdata)
+    pref = Reference.from_pmd(ppath)
+    from simple_mmd_renderer_amd import pmx as pmxmod2
+    ppm = pmxmod2.load_pmd(ppath)
+    prng = np.random.RandomState(8)
+    nfp = 4
+    prates = prng.choice([0, 0.3, 1.0, -0.5, 0.7], (nfp, ppm.flat.nm)).astype(np.float32)
+    ppal = synth.make_palettes(ppm.flat, np.arange(nfp) * 5)
+    pposes = np.zeros((nfp, ppm.flat.nb, 8), np.float32)
+    pposes[..., 0:3] = prng.uniform(-1, 1, (nfp, ppm.flat.nb, 3))
+    pq = prng.normal(size=(nfp, ppm.flat.nb, 4))
+    pposes[..., 4:8] = pq / np.linalg.norm(pq, axis=-1, keepdims=True)
+    ppos, pnrm, prig = [], [], []
+    for f in range(nfp):
+        a_, b_, _ = pref.run(prates[f], ppal[f])
+        ppos.append(a_); pnrm.append(b_)
+        for b in range(ppm.flat.nb):
+            pref.set_bone_pose(b, pposes[f, b, 0:3], pposes[f, b, 4:8])
+        pref.set_morphs(np.zeros(ppm.flat.nm, np.float32))
+        pref.pose()
+        prig.append(pref.get_palette())
+    pref.close()
+    np.savez_compressed(os.path.join(OUT, "pmd_small_expect.npz"), rates=prates, palette=ppal, poses=pposes,
+                        expect_pos=np.stack(ppos), expect_nrm=np.stack(pnrm), expect_rig_palette=np.stack(prig))
+    print(f"{'pmd_small.pmd':28s} {len(pdata) / 1024:7.1f} KB + expectations")
+
     # G13 config-1 plumbing: 20 000 verts / 150 bones / 30 morphs / 600 frames, checksums only.
     cfg = synth.CONFIGS["config1_20k"]
     m = synth.make_config("config1_20k")

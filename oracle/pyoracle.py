@@ -334,20 +334,26 @@ class Reference:
         return self.get_palette()
 
     @classmethod
-    def from_pmx(cls, path: str) -> "Reference":
+    def from_pmd(cls, path: str) -> "Reference":
+        """libmmd's own PmdReader + Poser on a file (the older format)."""
+        return cls.from_pmx(path, entry="mmdref_create_from_pmd")
+
+    @classmethod
+    def from_pmx(cls, path: str, entry: str = "mmdref_create_from_pmx") -> "Reference":
         """Load a .pmx through the reference's own FileReader + PmxReader (+ Normalize) + Poser."""
         if not reference_available():
             raise RuntimeError("oracle/_ref/libmmd_ref.so not built (needs /root/reference)")
         self = cls.__new__(cls)
         lib = C.CDLL(REF_SO)
-        lib.mmdref_create_from_pmx.restype = C.c_void_p
+        create = getattr(lib, entry)
+        create.restype = C.c_void_p
         lib.mmdref_last_error.restype = C.c_char_p
         lib.mmdref_time_frames.restype = C.c_double
         lib.mmdref_time_crowd.restype = C.c_double
         lib.mmdref_time_pmx_load.restype = C.c_double
-        h = lib.mmdref_create_from_pmx(str(path).encode())
+        h = create(str(path).encode())
         if not h:
-            raise RuntimeError("libmmd PmxReader: " + (lib.mmdref_last_error() or b"").decode("utf-8", "replace"))
+            raise RuntimeError("libmmd reader: " + (lib.mmdref_last_error() or b"").decode("utf-8", "replace"))
         self.lib, self.h = lib, C.c_void_p(h)
         nv, nb, nm, nt = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib.mmdref_get_counts(self.h, C.byref(nv), C.byref(nb), C.byref(nm), C.byref(nt))

@@ -211,6 +211,22 @@ void *mmdref_create_from_pmx(const char *path) {
     return r;
 }
 
+// The same through libmmd's PmdReader (the older format).
+void *mmdref_create_from_pmd(const char *path) {
+    Ref *r = new Ref;
+    try {
+        std::string p(path);
+        mmd::FileReader file(std::wstring(p.begin(), p.end()));
+        mmd::PmdReader(file).ReadModel(r->model);
+        r->poser = new mmd::Poser(r->model);
+    } catch (const std::exception &e) {
+        g_ref_err = e.what();
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+
 void mmdref_get_counts(void *h, uint32_t *nv, uint32_t *nb, uint32_t *nm, uint32_t *ntri) {
     Ref *r = static_cast<Ref *>(h);
     *nv = uint32_t(r->model.GetVertexNum()); *nb = uint32_t(r->model.GetBoneNum());

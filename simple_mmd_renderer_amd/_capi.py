@@ -94,6 +94,8 @@ SIGNATURES = {
     "mmdx_bench_store_pattern": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, _f32p]),
     "mmdx_pmx_parse": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mmdx_pmx_load_file": (C.c_int32, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "mmdx_pmd_parse": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mmdx_pmd_load_file": (C.c_int32, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mmdx_pmx_destroy": (None, [C.c_void_p]),
     "mmdx_pmx_get_info": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mmdx_pmx_get_model_desc": (C.c_int32, [C.c_void_p, C.POINTER(ModelDesc)]),

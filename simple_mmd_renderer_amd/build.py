@@ -16,9 +16,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdx.so")
-SOURCES = ["api.cpp", "kernels.hip", "plan.cpp", "pmx.cpp", "vmd.cpp", "error.cpp",
+SOURCES = ["api.cpp", "kernels.hip", "plan.cpp", "pmx.cpp", "pmd.cpp", "vmd.cpp", "error.cpp",
            "rig.cpp", "rig_api.cpp", "rig_kernels.hip"]
-HEADERS = ["kernels.hpp", "plan.hpp", "error.hpp", "vmd.hpp", "rig.hpp", "rig_kernels.hpp", os.path.join("..", "..", "include", "mmdx.h")]
+HEADERS = ["kernels.hpp", "plan.hpp", "error.hpp", "vmd.hpp", "rig.hpp", "rig_kernels.hpp", "pmx.hpp", os.path.join("..", "..", "include", "mmdx.h")]
 ARCH = "gfx950"
 
 

@@ -288,15 +288,21 @@ def _arr(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
 
 
-def load_pmx(source) -> PmxModel:
-    """Parse a PMX 2.0 file (path or bytes) with the C-ABI loader (csrc/pmx.cpp)."""
+def load_pmd(source) -> PmxModel:
+    """Parse a PMD 1.0 file (path or bytes) with the C-ABI loader (csrc/pmd.cpp); same result type."""
+    return load_pmx(source, fmt="pmd")
+
+
+def load_pmx(source, fmt: str = "pmx") -> PmxModel:
+    """Parse a PMX 2.0 (or, fmt="pmd", a PMD 1.0) file (path or bytes) with the C-ABI loader."""
     lib = api.lib()
     h = C.c_void_p()
+    parse, load = (lib.mmdx_pmx_parse, lib.mmdx_pmx_load_file) if fmt == "pmx" else (lib.mmdx_pmd_parse, lib.mmdx_pmd_load_file)
     if isinstance(source, (bytes, bytearray)):
         buf = (C.c_char * len(source)).from_buffer_copy(bytes(source))
-        api.check(lib.mmdx_pmx_parse(buf, len(source), C.byref(h)))
+        api.check(parse(buf, len(source), C.byref(h)))
     else:
-        api.check(lib.mmdx_pmx_load_file(str(source).encode("utf-8"), C.byref(h)))
+        api.check(load(str(source).encode("utf-8"), C.byref(h)))
     try:
         info = PmxInfo()
         info.struct_size = C.sizeof(PmxInfo)

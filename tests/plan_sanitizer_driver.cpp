@@ -111,6 +111,50 @@ int main() {
     }
     std::printf("pmx fuzz: parsed=%d rejected=%d\n", ok, bad);
 
+    // PMD parser: a minimal valid file (2 vertices, 3 bones incl. an IK bone with two IK records, base morph
+    // + one morph), then byte-level fuzzing; whatever parses must also survive the skeleton compile
+    {
+        std::vector<uint8_t> f;
+        auto put = [&](const void *p, size_t n) { f.insert(f.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+        auto zeros = [&](size_t n) { f.insert(f.end(), n, 0); };
+        const float one = 1.0f;
+        put("Pmd", 3); put(&one, 4); zeros(276);
+        const uint32_t nvv = 2; put(&nvv, 4);
+        for (uint32_t i = 0; i < nvv; ++i) { float v[8] = {float(i), 1, 2, 0, 1, 0, 0.5f, 0.5f}; put(v, 32); const int16_t id[2] = {0, 1}; put(id, 4); const uint8_t w[2] = {60, 0}; put(w, 2); }
+        const uint32_t nidx = 0, nmat = 0; put(&nidx, 4); put(&nmat, 4);
+        const uint16_t nbb = 3; put(&nbb, 2);
+        for (uint16_t b = 0; b < nbb; ++b) { uint8_t rec[39] = {0}; rec[0] = uint8_t('a' + b); const int16_t par = int16_t(b) - 1; std::memcpy(rec + 20, &par, 2); rec[24] = b == 2 ? 2 : 0; put(rec, 39); }
+        const uint16_t nikk = 2; put(&nikk, 2);
+        for (uint16_t k = 0; k < nikk; ++k) { const int16_t ib = 2, tg = 1; put(&ib, 2); put(&tg, 2); const uint8_t len = 1; put(&len, 1); const uint16_t it = 3; put(&it, 2); put(&one, 4); const uint16_t ch = k; put(&ch, 2); }
+        const uint16_t nmm = 2; put(&nmm, 2);
+        for (uint16_t k = 0; k < nmm; ++k) { uint8_t hd[25] = {0}; hd[0] = 'm'; const uint32_t cnt = 1; std::memcpy(hd + 20, &cnt, 4); hd[24] = uint8_t(k); put(hd, 25); const uint32_t idx = 0; put(&idx, 4); float o[3] = {0.1f, 0.2f, 0.3f}; put(o, 12); }
+        zeros(1 + 1 + 4);
+        mmdx_pmx_t h = nullptr;
+        if (mmdx_pmd_parse(f.data(), f.size(), &h) != MMDX_OK) { std::printf("valid pmd rejected: %s\n", mmdx_last_error_string()); return 14; }
+        mmdx_pmx_info pi{}; pi.struct_size = sizeof(pi);
+        mmdx_pmx_get_info(h, &pi);
+        if (pi.n_vertices != 2 || pi.n_bones != 4 || pi.n_morphs != 2) { std::printf("pmd counts %u %u %u\n", pi.n_vertices, pi.n_bones, pi.n_morphs); return 15; }
+        mmdx_pmx_destroy(h);
+        int pok = 0, pbad = 0;
+        for (int it = 0; it < 4000; ++it) {
+            std::vector<uint8_t> g = f;
+            const int nmut = 1 + int(rng() % 4);
+            for (int k = 0; k < nmut; ++k) g[rng() % g.size()] = uint8_t(rng());
+            if (it % 7 == 0) g.resize(rng() % g.size());
+            h = nullptr;
+            if (mmdx_pmd_parse(g.data(), g.size(), &h) == MMDX_OK) {
+                ++pok;
+                mmdx_skeleton_desc sd{};
+                mmdx_pmx_get_skeleton_desc(h, &sd);
+                mmdx::SkeletonPlan sp;
+                std::string err;
+                (void)mmdx::build_skeleton(sd, sp, err);
+                mmdx_pmx_destroy(h);
+            } else ++pbad;
+        }
+        std::printf("pmd fuzz: parsed=%d rejected=%d\n", pok, pbad);
+    }
+
     // VMD parser: a small valid motion, then the same byte-level fuzzing
     std::vector<uint8_t> m(50, 0);
     std::memcpy(m.data(), "Vocaloid Motion Data 0002", 25);

@@ -16,6 +16,7 @@ def test_plan_builder_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-std=c++17"] + SAN + [os.path.join(ROOT, "tests", "plan_sanitizer_driver.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "plan.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "pmx.cpp"),
+                                         os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "pmd.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "vmd.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "rig.cpp"),
                                          os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", "error.cpp"),
