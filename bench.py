@@ -90,12 +90,13 @@ def main():
 
     dm = DeformModel(model)
     info = dm.info
-    d_pal = DeviceBuffer.from_numpy(pals)
-    d_w = DeviceBuffer.from_numpy(rates)
     # Output arrays through the engine's placement-aware allocator: on MI355X the store rate of the crowd
     # pattern depends on where the driver puts the arrays (bimodal); set-up work,
-    # outside the timed region.  --plain-alloc takes whatever hipMalloc hands out first.
+    # outside the timed region, and done first: the big arrays of a young process land in the fast mode
+    # within a try or two (tools/shop_probe.py).  --plain-alloc takes whatever hipMalloc hands out first.
     d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else 64)
+    d_pal = DeviceBuffer.from_numpy(pals)
+    d_w = DeviceBuffer.from_numpy(rates)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
 
     def step():
