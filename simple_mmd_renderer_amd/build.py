@@ -64,24 +64,27 @@ HOST_DIR = os.path.join(HERE, "host")
 HOST_EXAMPLE = os.path.join(HOST_DIR, "frame_loop_example")
 
 
-def build_host_example(force: bool = False) -> str:
-    """The C++ host mirror's runnable example (g++ only: the host side needs no HIP headers)."""
-    src = os.path.join(HOST_DIR, "frame_loop_example.cpp")
+def build_host_example(force: bool = False, name: str = "frame_loop_example") -> str:
+    """The C++ host mirror's runnable examples (g++ only: the host side needs no HIP headers):
+    frame_loop_example (palette from the host) and motion_example (.pmx/.pmd + .vmd, everything on the GPU)."""
+    src = os.path.join(HOST_DIR, name + ".cpp")
     hdr = os.path.join(HOST_DIR, "mmdx_poser.hpp")
-    if (not force and os.path.exists(HOST_EXAMPLE) and
-            all(os.path.getmtime(d) <= os.path.getmtime(HOST_EXAMPLE) for d in (src, hdr, LIB))):
-        return HOST_EXAMPLE
+    exe = os.path.join(HOST_DIR, name)
+    if (not force and os.path.exists(exe) and
+            all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in (src, hdr, LIB))):
+        return exe
     build()
     cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", src,
            "-I" + os.path.join(HERE, "..", "include"), "-L" + HERE, "-lmmdx", "-Wl,-rpath,$ORIGIN/..",
-           "-o", HOST_EXAMPLE]
+           "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("g++ failed for host/frame_loop_example.cpp")
-    return HOST_EXAMPLE
+        raise RuntimeError("g++ failed for host/%s.cpp" % name)
+    return exe
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host_example(force="--force" in sys.argv))
+    print(build_host_example(force="--force" in sys.argv, name="motion_example"))

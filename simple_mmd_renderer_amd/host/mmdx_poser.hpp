@@ -5,12 +5,17 @@
 //   mmd::Poser::pose_image, SetMorphPose, ResetPosing (rates only), Deform    L/motion/poser.inl:17-43
 //   the palette hook PhysicsReactor::GetPoserBoneImage(...).skinning_matrix_   L/motion/physics.inl:32-40
 //   the viewer's struct Vertex + UpdateDeformedVertices()                      main.cpp:50-54, :821-863
+//   SetBonePose, PrePhysicsPosing / PostPhysicsPosing (bone solve -> palette)  L/motion/poser_impl.inl:362-394, :466-469
+//   mmd::MotionPlayer(motion, poser)::SeekFrame                                L/motion/poser_impl.inl:522-548
+//   the loaders' entry points (PmxReader / PmdReader / VmdReader ::Read*)      through Poser::FromFile, Motion
 // Same names and argument meaning; errors surface as mmdx::Error (the reference's loaders throw
 // mmd::exception, its Deform has no error path at all).
 #pragma once
 
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -75,12 +80,58 @@ public:
             for (int k = 0; k < 4; ++k) palette_[size_t(b) * 16 + k * 5] = 1.0f;
         Deform();  // the reference's constructor ends with ResetPosing(); Deform() (poser_impl.inl:126-127)
     }
-    ~Poser() { mmdx_model_destroy(model_); }
+    // From a .pmx / .pmd file through the bundled loaders: the GPU model AND the rig (bone solve on the
+    // device, so PrePhysicsPosing() works without libmmd).  Names are kept for MotionPlayer.
+    static Poser *FromFile(const std::string &path) {
+        mmdx_pmx_t pmx = nullptr;
+        const bool pmd = path.size() > 4 && (path.substr(path.size() - 4) == ".pmd" || path.substr(path.size() - 4) == ".PMD");
+        check(pmd ? mmdx_pmd_load_file(path.c_str(), &pmx) : mmdx_pmx_load_file(path.c_str(), &pmx));
+        Poser *p = nullptr;
+        try {
+            p = new Poser(pmx);
+        } catch (...) {
+            mmdx_pmx_destroy(pmx);
+            throw;
+        }
+        mmdx_pmx_destroy(pmx);
+        return p;
+    }
+    ~Poser() {
+        if (skeleton_) mmdx_skeleton_destroy(skeleton_);
+        mmdx_model_destroy(model_);
+    }
     Poser(const Poser &) = delete;
     Poser &operator=(const Poser &) = delete;
 
-    void ResetPosing() { std::fill(morph_rates_.begin(), morph_rates_.end(), 0.0f); }
+    void ResetPosing() {
+        std::fill(morph_rates_.begin(), morph_rates_.end(), 0.0f);
+        for (uint32_t b = 0; b < uint32_t(bone_poses_.size() / 8); ++b) {
+            float *q = bone_poses_.data() + size_t(b) * 8;
+            q[0] = q[1] = q[2] = q[3] = q[4] = q[5] = q[6] = 0.0f; q[7] = 1.0f;
+        }
+        if (skeleton_) { PrePhysicsPosing(); PostPhysicsPosing(); }       // as the reference does (:138-139)
+    }
     void SetMorphPose(size_t index, float weight) { morph_rates_.at(index) = weight; }
+    // = Poser::SetBonePose(index, Motion::BonePose(translation, rotation)); quaternion x, y, z, w
+    void SetBonePose(size_t index, const float translation[3], const float rotation[4]) {
+        float *q = bone_poses_.data() + index * 8;
+        if (index * 8 + 8 > bone_poses_.size()) throw Error(MMDX_ERR_BAD_INDEX, "SetBonePose: bone index out of range");
+        std::memcpy(q, translation, 12); q[3] = 0.0f; std::memcpy(q + 4, rotation, 16);
+    }
+    // Bone solve on the device (bone morphs, append bones, IK included): local poses -> skinning matrices.
+    // Only for posers that own a rig (FromFile); physics, if any, stays with the host, which overwrites
+    // its bones' rows through SkinningMatrix() between the two calls exactly as mmd-bullet does today.
+    void PrePhysicsPosing() {
+        if (!skeleton_) throw Error(MMDX_ERR_UNSUPPORTED, "this Poser has no rig: fill SkinningMatrix() yourself");
+        check(mmdx_skeleton_solve_morphed(skeleton_, model_, 1, bone_poses_.data(), nm_ ? morph_rates_.data() : nullptr,
+                                          MMDX_WEIGHTS_SHARED, palette_.data()));
+    }
+    void PostPhysicsPosing() {}   // the device solve covers both of the reference's bone lists in order
+
+    const std::vector<std::string> &bone_names() const { return bone_names_; }
+    const std::vector<std::string> &morph_names() const { return morph_names_; }
+    std::vector<float> &morph_rates() { return morph_rates_; }
+    std::vector<float> &bone_poses() { return bone_poses_; }      // [NB][8]: t.xyz, 0, q.xyzw
 
     // What a PhysicsReactor-derived tap reads out of the reference Poser after PostPhysicsPosing():
     // float[16], row-vector convention, translation in elements 12..14.
@@ -104,11 +155,94 @@ public:
 
     mmdx_model_t handle() const { return model_; }
     uint32_t vertex_count() const { return nv_; }
+    uint32_t bone_count() const { return nb_; }
+    uint32_t morph_count() const { return nm_; }
 
 private:
-    uint32_t nv_, nb_, nm_;
+    explicit Poser(mmdx_pmx_t pmx) {
+        mmdx_model_desc d;
+        check(mmdx_pmx_get_model_desc(pmx, &d));
+        nv_ = d.n_vertices; nb_ = d.n_bones; nm_ = d.n_morphs;
+        check(mmdx_model_create(&d, &model_));
+        mmdx_skeleton_desc sd;
+        check(mmdx_pmx_get_skeleton_desc(pmx, &sd));
+        const mmdx_status st = mmdx_skeleton_create(&sd, &skeleton_);
+        if (st != MMDX_OK) { mmdx_model_destroy(model_); throw Error(st, mmdx_last_error_string()); }
+        char buf[1024];
+        for (uint32_t b = 0; b < nb_; ++b) { check(mmdx_pmx_get_name(pmx, MMDX_PMX_NAME_BONE, b, buf, sizeof(buf))); bone_names_.push_back(buf); }
+        for (uint32_t m = 0; m < nm_; ++m) { check(mmdx_pmx_get_name(pmx, MMDX_PMX_NAME_MORPH, m, buf, sizeof(buf))); morph_names_.push_back(buf); }
+        pose_image.coordinates.resize(nv_);
+        pose_image.normals.resize(nv_);
+        morph_rates_.assign(nm_, 0.0f);
+        palette_.assign(size_t(nb_) * 16, 0.0f);
+        bone_poses_.assign(size_t(nb_) * 8, 0.0f);
+        ResetPosing();
+        Deform();
+    }
+
+    uint32_t nv_ = 0, nb_ = 0, nm_ = 0;
     mmdx_model_t model_ = nullptr;
-    std::vector<float> morph_rates_, palette_;
+    mmdx_skeleton_t skeleton_ = nullptr;
+    std::vector<float> morph_rates_, palette_, bone_poses_;
+    std::vector<std::string> bone_names_, morph_names_;
+};
+
+// = mmd::Motion filled by VmdReader::ReadMotion
+class Motion {
+public:
+    explicit Motion(const std::string &vmd_path) { check(mmdx_vmd_load_file(vmd_path.c_str(), &vmd_)); }
+    ~Motion() { mmdx_vmd_destroy(vmd_); }
+    Motion(const Motion &) = delete;
+    Motion &operator=(const Motion &) = delete;
+    mmdx_vmd_t handle() const { return vmd_; }
+    uint32_t GetLength() const {
+        mmdx_vmd_info info;
+        info.struct_size = sizeof(info);
+        check(mmdx_vmd_get_info(vmd_, &info));
+        return info.max_frame;
+    }
+
+private:
+    mmdx_vmd_t vmd_ = nullptr;
+};
+
+// = mmd::MotionPlayer: associates the motion's tracks with the poser's bones and morphs by name at
+// construction; SeekFrame evaluates every track at `frame` (on the device) and hands the results to the
+// poser through SetMorphPose / SetBonePose, like the reference's loop over its name maps.
+class MotionPlayer {
+public:
+    MotionPlayer(const Motion &motion, Poser &poser) : poser_(poser) {
+        std::vector<const char *> bn, mn;
+        for (const std::string &s : poser.bone_names()) bn.push_back(s.c_str());
+        for (const std::string &s : poser.morph_names()) mn.push_back(s.c_str());
+        check(mmdx_vmd_bind_bones(motion.handle(), uint32_t(bn.size()), bn.data(), &bones_));
+        const mmdx_status st = mmdx_vmd_bind_morphs(motion.handle(), uint32_t(mn.size()), mn.data(), &morphs_);
+        if (st != MMDX_OK) { mmdx_bone_motion_destroy(bones_); throw Error(st, mmdx_last_error_string()); }
+        uint32_t nb = 0, mapped = 0, keys = 0, curves = 0;
+        check(mmdx_bone_motion_get_info(bones_, &nb, &mapped, &keys, &curves));
+        mapped_bones_ = mapped;
+    }
+    ~MotionPlayer() {
+        mmdx_bone_motion_destroy(bones_);
+        mmdx_morph_motion_destroy(morphs_);
+    }
+    MotionPlayer(const MotionPlayer &) = delete;
+    MotionPlayer &operator=(const MotionPlayer &) = delete;
+
+    void SeekFrame(size_t frame) {
+        const uint32_t f = uint32_t(frame);
+        if (poser_.morph_count())
+            check(mmdx_morph_motion_eval(morphs_, poser_.handle(), 1, &f, 0, poser_.morph_rates().data()));
+        if (poser_.bone_count())
+            check(mmdx_bone_motion_eval(bones_, poser_.handle(), 1, &f, 0, poser_.bone_poses().data()));
+    }
+    uint32_t mapped_bones() const { return mapped_bones_; }
+
+private:
+    Poser &poser_;
+    mmdx_bone_motion_t bones_ = nullptr;
+    mmdx_morph_motion_t morphs_ = nullptr;
+    uint32_t mapped_bones_ = 0;
 };
 
 }  // namespace mmdx

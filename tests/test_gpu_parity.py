@@ -443,6 +443,49 @@ def test_cpp_host_mirror_frame_loop():
     assert again.stdout == r.stdout            # deterministic, run to run
 
 
+def test_cpp_motion_example_matches_python_path(tmp_path):
+    """host/motion_example.cpp (mmd::Poser / Motion / MotionPlayer mirror: .pmx + .vmd -> SeekFrame ->
+    PrePhysicsPosing -> Deform -> UpdateDeformedVertices, all on the GPU) against the same steps driven
+    from Python over the same C ABI: identical checksums."""
+    import subprocess
+    from simple_mmd_renderer_amd import build, pmx, vmd
+    nb = 40
+    rig = synth.make_ik_rig(nb, 11, n_ik=3, n_append=4)
+    m = synth.make_model(600, nb, 5, 60, seed=12)
+    m.bone_pos, m.bone_parent = rig[0].copy(), rig[1].astype(m.bone_parent.dtype)
+    bnames = ["骨%d" % b for b in range(nb)]
+    mnames = ["表情%d" % k for k in range(m.nm)]
+    (tmp_path / "m.pmx").write_bytes(pmx.write_pmx(m, pmx.PmxWriteOptions(rig=rig, bone_names=bnames, morph_names=mnames)))
+    rng = np.random.RandomState(5)
+    mk = [(n, int(f), float(np.float32(rng.uniform(0, 1)))) for n in mnames[:4] for f in (0, 7, 19)]
+    (tmp_path / "m.vmd").write_bytes(vmd.write_vmd(synth.make_bone_keys(bnames[:30], 13, keys_per=4, span=24), mk))
+    frames = 25
+    exe = build.build_host_example(name="motion_example")
+    r = subprocess.run([exe, str(tmp_path / "m.pmx"), str(tmp_path / "m.vmd"), str(frames)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0 and "checksum=" in r.stdout, r.stdout + r.stderr
+    # the same through the Python binding
+    pm = pmx.load_pmx(str(tmp_path / "m.pmx"))
+    v = vmd.Vmd(str(tmp_path / "m.vmd"))
+    bm, mm, sk = v.bind_bones(pm.bone_names), v.bind_morphs(pm.morph_names), pm.skeleton()
+
+    def fnv(a):
+        h = 1469598103934665603
+        for byte in np.ascontiguousarray(a).view(np.uint8).ravel().tolist():
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    h = 0
+    with DeformModel(pm.flat) as dm:
+        for f in range(frames):
+            rates = mm.eval([f], dm)[0]
+            pal = sk.solve(bm.eval([f], dm), dm, morph_weights=rates)[0]
+            _pos, nrm = dm.deform(rates, pal)
+            v32 = dm.deform_vertex32(rates, pal, 0.1)
+            h = (h * 31 + fnv(v32) + fnv(nrm)) & 0xFFFFFFFFFFFFFFFF
+    want = "frames=%d nv=%d nb=%d mapped_bones=30 checksum=%016x" % (frames, pm.flat.nv, nb, h)
+    assert r.stdout.strip() == want
+
+
 def test_pmx_file_to_gpu_end_to_end():
     """tests/golden/pmx_small.pmx -> this repo's PMX loader -> mmdx_model_create -> deform, against what
     libmmd (PmxReader + Normalize + Poser::Deform + repack) produced from the same file."""

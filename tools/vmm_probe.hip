@@ -89,15 +89,19 @@ int main() {
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice;
     CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     std::printf("recommended granularity %zu\n", gran);
-    // per-array or per-pair?  six arrays, every single one alone and every ordered pair
-    void *arr[6];
-    for (int i = 0; i < 6; ++i) CK(hipMalloc(&arr[i], bytes));
-    for (int i = 0; i < 6; ++i) std::printf("array %d alone: %6.0f GB/s\n", i, run(arr[i], nullptr));
-    for (int i = 0; i < 6; ++i) {
-        std::printf("a = %d:", i);
-        for (int j = 0; j < 6; ++j) std::printf(" %6.0f", i == j ? 0.0f : run(arr[i], arr[j]));
-        std::printf("   (b = 0..5)\n");
+    // hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous backing.  Interleaved with plain
+    // hipMalloc trials in the same (increasingly churned) process.
+    for (int t = 0; t < 12; ++t) {
+        void *a, *b;
+        CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+        const float plain = run(a, b);
+        CK(hipFree(a)); CK(hipFree(b));
+        hipError_t e1 = hipExtMallocWithFlags(&a, bytes, hipDeviceMallocContiguous);
+        hipError_t e2 = hipExtMallocWithFlags(&b, bytes, hipDeviceMallocContiguous);
+        if (e1 != hipSuccess || e2 != hipSuccess) { std::printf("contiguous alloc failed: %s %s\n", hipGetErrorString(e1), hipGetErrorString(e2)); return 1; }
+        const float contig = run(a, b);
+        CK(hipFree(a)); CK(hipFree(b));
+        std::printf("trial %2d: hipMalloc %6.0f GB/s   contiguous %6.0f GB/s\n", t, plain, contig);
     }
-    for (int i = 0; i < 6; ++i) CK(hipFree(arr[i]));
     return 0;
 }
