@@ -300,6 +300,25 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     for b in (d_pal, d_w, d_a, d_b):
         b.free()
 
+    # config 3' (SURVEY 8d): the same 1024-instance crowd with PER-INSTANCE morph weights (every instance its
+    # own facial state): the fused gather path, 4 instances per pass over a vertex's morph row.
+    try:
+        ni = 1024
+        fr_i = (np.arange(ni) * 7) % 600
+        d_wi = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, fr_i))
+        d_pali = DeviceBuffer.from_numpy(synth.make_palettes(model3, fr_i))
+        d_ai, d_bi, _pl = dm3.alloc_outputs(api.OUT_SOA, ni, 16)
+        ms_i = time_calls(dm3, lambda: dm3.deform_batched_raw(ni, d_wi.ptr, d_pali.ptr, d_ai.ptr, d_bi.ptr, api.OUT_SOA,
+                                                              flags_dev), 10)
+        bi = static + table + ni * (model3.nv * 24 + model3.nb * 48 + model3.nm * 4)
+        out["config3prime_per_instance_morphs"] = {"ms_per_call": ms_i, "vertices_per_s": ni * model3.nv / (ms_i * 1e-3),
+                                                   "algorithmic_GBs": bi / (ms_i * 1e-3) / 1e9,
+                                                   "frac_of_8TBs": bi / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        for b in (d_wi, d_pali, d_ai, d_bi):
+            b.free()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["config3prime_per_instance_morphs"] = {"error": repr(e)}
+
     # The palette producer for the crowd: a 300-track bone motion with Bezier curves
     # -> local poses -> FK palettes for 1024 instances at their own frames, all in HBM; then the whole
     # motion -> vertices step (poses + palettes + morph pass + deform).  CPU: libmmd doing the same bone
