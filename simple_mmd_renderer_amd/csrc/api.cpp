@@ -424,16 +424,24 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     }
     dp.out_aligned = ((reinterpret_cast<uintptr_t>(dp.out_a) | reinterpret_cast<uintptr_t>(dp.out_b)) & 15) == 0;
 
+    // ---- workgroup shape ------------------------------------------------------------------------------
+    // 256 threads / two vertex slots per lane everywhere except the per-instance-morph path: there one slot
+    // per lane (512 threads) leaves the registers to serve 8 instances per walk over a morph row.
+    int threads = env_int("MMDX_THREADS", morph == kMorphFused4 ? 512 : 256) == 512 ? 512 : 256;
+    if (morph == kMorphFused4 && threads == 512) {   // tiles with hundreds of bones: 8 palettes do not fit, 4 may
+        uint32_t so, wo;
+        if (deform_lds_bytes(512, layout, morph, 8, p.max_tile_bones, p.ns, &so, &wo) > 160 * 1024) threads = 256;
+    }
     // ---- group size (instances per workgroup) from the LDS budget ---------------------------------
-    const uint32_t gmin = morph == kMorphFused4 ? 4u : 1u;
+    const uint32_t gmin = morph == kMorphFused4 ? (threads == 512 ? 8u : 4u) : 1u;
     uint32_t group = gmin;
     if (morph != kMorphFused1) {
-        const uint32_t target = uint32_t(env_int("MMDX_LDS_TARGET", 42 * 1024));
+        const uint32_t target = uint32_t(env_int("MMDX_LDS_TARGET", (morph == kMorphFused4 ? 64 : 42) * 1024));
         uint32_t so, wo;
-        const size_t fixed = deform_lds_bytes(layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);
+        const size_t fixed = deform_lds_bytes(threads, layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);
         const size_t per = size_t(p.max_tile_bones) * 48;
         uint32_t g = target > fixed ? uint32_t((target - fixed) / per) : 0u;
-        g = std::min(g, 32u);
+        g = std::min(g, morph == kMorphFused4 ? 16u : 32u);
         if (g >= 8) g &= ~3u;   // measured: 16 beats 17 (even split of 1024 instances, aligned strides)
         g = std::max(g / gmin * gmin, gmin);
         const uint32_t ni_up = (ni + gmin - 1) / gmin * gmin;
@@ -449,13 +457,13 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (forced > 0) group = std::max(uint32_t(forced) / gmin * gmin, gmin);
     }
     dp.group = group;
-    const size_t lds = deform_lds_bytes(layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off);
+    const size_t lds = deform_lds_bytes(threads, layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off);
     if (lds > 160 * 1024)
         return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(lds) + " bytes of LDS (> 160 KiB): "
                                           "too many distinct bones in one vertex tile / too many morph slots");
 
     if (pev) HIP_TRY(hipEventRecord(pev[0], st));
-    HIP_TRY(launch_deform(env_int("MMDX_THREADS", 256), int(layout), morph, p.f16, dp, p.ntiles, lds, st));
+    HIP_TRY(launch_deform(threads, int(layout), morph, p.f16, dp, p.ntiles, lds, st));
     if (pev) {
         HIP_TRY(hipEventRecord(pev[1], st));
         if (m->prof_has_morph.size() <= m->prof_calls) m->prof_has_morph.resize(m->prof_calls + 1);

@@ -518,32 +518,46 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         }
         run_instance(0, cxy, cz);
     } else {
-        // Slot weights of ONE instance quad live in LDS at a time ((NS+1) x float4): the group can then
-        // be large (static data, palettes and the prologue amortise over more instances) without the
-        // weights eating the LDS.
+        // Slot weights of kQuads instance quads live in LDS at a time (kQuads x (NS+1) x float4): one pass over
+        // a vertex's morph row then serves 4*kQuads instances, so the table is walked (and its L2 latency paid)
+        // that much less often.  One slot per lane (512 threads) has the registers for two quads; two slots per
+        // lane do not (a third wave per SIMD is worth more there: measured).  A missing second quad is staged as
+        // zeros: weight +0 adds nothing, bit for bit.
+        constexpr int kQuads = VPT == 1 ? 2 : 1, kPack = 4 * kQuads;
         float4 *wq = reinterpret_cast<float4 *>(smem + p.w_off);
-        for (uint32_t g0 = 0; g0 < gcount; g0 += 4) {
-            v2f dxy[VPT][4];
-            float dz[VPT][4];
-            if (g0) __syncthreads();                       // everyone is done with the previous quad's weights
+        const uint32_t wstride = p.ns + 1;
+        for (uint32_t g0 = 0; g0 < gcount; g0 += kPack) {
+            v2f dxy[VPT][kPack];
+            float dz[VPT][kPack];
+            if (g0) __syncthreads();                       // everyone is done with the previous weights
             {
-                const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t((inst0 + g0) / 4) * (p.ns + 1);
-                for (uint32_t i = tid; i <= p.ns; i += THREADS) wq[i] = src[i];
+                const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t((inst0 + g0) / 4) * wstride;
+                for (uint32_t i = tid; i < wstride; i += THREADS) {
+                    wq[i] = src[i];
+                    if constexpr (kQuads == 2)
+                        wq[wstride + i] = g0 + 4 < gcount ? src[wstride + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dxy[k][j] = v2f{0.f, 0.f}; dz[k][j] = 0.f; }
+                for (int j = 0; j < kPack; ++j) { dxy[k][j] = v2f{0.f, 0.f}; dz[k][j] = 0.f; }
+                auto weights = [&](uint32_t slot, float (&w)[kPack]) {
+                    const float4 a4 = wq[slot];
+                    w[0] = a4.x; w[1] = a4.y; w[2] = a4.z; w[3] = a4.w;
+                    if constexpr (kQuads == 2) {
+                        const float4 b4 = wq[wstride + slot];
+                        w[4] = b4.x; w[5] = b4.y; w[6] = b4.z; w[7] = b4.w;
+                    }
+                };
 #ifdef MMDX_ABLATE
                 if (p.ablate & 128u) {           // no morph gather at all
                 } else if (p.ablate & 256u) {    // gather without the LDS weight lookups
                     for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
                         const float w = __uint_as_float(slot | 0x3f000000u);
-                        dxy[k][0] += oxy * w; dz[k][0] += oz * w;
-                        dxy[k][1] += oxy * w; dz[k][1] += oz * w;
-                        dxy[k][2] += oxy * w; dz[k][2] += oz * w;
-                        dxy[k][3] += oxy * w; dz[k][3] += oz * w;
+#pragma unroll
+                        for (int j = 0; j < kPack; ++j) { dxy[k][j] += oxy * w; dz[k][j] += oz * w; }
                     });
                 } else
 #endif
@@ -552,24 +566,23 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
                     // the image bit-for-bit unchanged: the skip needs no branch.
                     for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
-                        const float4 w = wq[slot];
-                        dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x;
-                        dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y;
-                        dxy[k][2] += oxy * w.z; dz[k][2] += oz * w.z;
-                        dxy[k][3] += oxy * w.w; dz[k][3] += oz * w.w;
+                        float w[kPack];
+                        weights(slot, w);
+#pragma unroll
+                        for (int j = 0; j < kPack; ++j) { dxy[k][j] += oxy * w[j]; dz[k][j] += oz * w[j]; }
                     });
                 } else {
                     for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
-                        const float4 w = wq[slot];
-                        if (!(w.x < kMorphEps)) { dxy[k][0] += oxy * w.x; dz[k][0] += oz * w.x; }
-                        if (!(w.y < kMorphEps)) { dxy[k][1] += oxy * w.y; dz[k][1] += oz * w.y; }
-                        if (!(w.z < kMorphEps)) { dxy[k][2] += oxy * w.z; dz[k][2] += oz * w.z; }
-                        if (!(w.w < kMorphEps)) { dxy[k][3] += oxy * w.w; dz[k][3] += oz * w.w; }
+                        float w[kPack];
+                        weights(slot, w);
+#pragma unroll
+                        for (int j = 0; j < kPack; ++j)
+                            if (!(w[j] < kMorphEps)) { dxy[k][j] += oxy * w[j]; dz[k][j] += oz * w[j]; }
                     });
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kPack; ++j) {
                 if (g0 + j < gcount) {
                     v2f cxy[VPT];
                     float cz[VPT];
@@ -730,14 +743,14 @@ KernelFn pick(int threads, int layout, int morph, bool f16) {
 
 }  // namespace
 
-size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
+size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
                         uint32_t *stage_off, uint32_t *w_off) {
     size_t off = size_t(group) * max_tile_bones * 48;
     *stage_off = uint32_t(off);
     off += 2 * size_t(stage_bytes(layout));
     *w_off = uint32_t(off);
     if (morph == kMorphFused1) off += (size_t(ns + 1) * 4 + 15) / 16 * 16;
-    else if (morph == kMorphFused4) off += size_t(ns + 1) * 16;   // one instance quad at a time
+    else if (morph == kMorphFused4) off += (threads == 512 ? 2 : 1) * size_t(ns + 1) * 16;   // one or two instance quads
     return off;
 }
 

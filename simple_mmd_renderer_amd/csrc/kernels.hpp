@@ -73,7 +73,7 @@ struct FlattenParams {
 };
 
 // Bytes of dynamic LDS the deform kernel needs for (layout, morph mode, group).
-size_t deform_lds_bytes(int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
+size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
                         uint32_t *stage_off, uint32_t *w_off);
 
 hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
