@@ -3,6 +3,8 @@ the real libmmd and (b) the C restatement on seeded inputs.  Bit-exact: integer/
 f32 arithmetic (kernels are built with -ffp-contract=off and keep the reference's operation order),
 so no tolerance is needed; the fp16 bandwidth variant is compared against the f32 oracle on
 f16-quantised inputs with its positions rounded to f16 once -- also bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,7 +226,8 @@ def _random_model(rng):
     return m
 
 
-@pytest.mark.parametrize("seed", range(24))
+# MMDX_SOAK_SEEDS=N widens the sweep (tools/ and the round's soak runs); the default keeps the suite short
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MMDX_SOAK_SEEDS", "24"))))
 def test_randomized_models_all_call_forms(oracle, seed):
     """Random sizes / class mixes / bone windows / morph tables (duplicates, groups of groups, ignored
     types) through every call form: single, batched per-instance, batched shared, vertex32."""
