@@ -208,6 +208,28 @@ def main():
                                   "kind": kind,
                                   "sample": f"{reps} x the full config-3 crowd step ({what}), "
                                             f"{secs:.1f} s of CPU work, single thread as the reference runs"}
+        # The same baseline on all host cores (one independent Poser per thread, the crowd's
+        # instances split among them) -- an extra, the contract's cpu_baseline stays the single-thread figure.
+        try:
+            if reference_available():
+                import concurrent.futures as cf
+                import time as _t
+                cores = min(len(os.sched_getaffinity(0)), 16)
+                per = ni // cores
+                with cf.ThreadPoolExecutor(cores) as ex:          # ctypes releases the GIL inside libmmd
+                    refs = list(ex.map(lambda _: Reference(model, normalize=True), range(cores)))
+                    t0 = _t.perf_counter()
+                    list(ex.map(lambda k: [refs[k].time_crowd(rates, pals[k * per:(k + 1) * per]) for _ in range(40)],
+                                range(cores)))
+                    wall = _t.perf_counter() - t0
+                for r_ in refs:
+                    r_.close()
+                result["cpu_baseline_all_cores"] = {
+                    "value": 40 * cores * per * model.nv / wall, "unit": "vertices/s", "cores": cores, "kind": "reference",
+                    "sample": f"40 x the config-3 crowd step, {cores} threads x {per} instances each with its own libmmd "
+                              f"Poser (every thread repeats the shared morph pass), {wall:.1f} s wall"}
+        except Exception as e:                               # pragma: no cover - reporting only
+            result["cpu_baseline_all_cores"] = {"error": repr(e)}
 
     # ---- other BASELINE configs (rank 0, N=1): reported, not the headline --------------------------
     if rank == 0 and world == 1 and not args.no_extras:
