@@ -322,6 +322,29 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     for b in (d_pal, d_w, d_a, d_b):
         b.free()
 
+    # config 3 with the viewer's interleaved 32-byte vertex as output (SURVEY 8d asks for it next to SoA):
+    # positions x 0.1, normals, uv passthrough -- Deform + UpdateDeformedVertices in one kernel.
+    try:
+        ni = 1024
+        d_w3 = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, 30)[0])
+        d_pal3 = DeviceBuffer.from_numpy(synth.make_palettes(model3, (np.arange(ni) * 3) % 1801))
+        d_v32, _none, _pl = dm3.alloc_outputs(api.OUT_VERTEX32, ni, 32)
+        dm3.profile_enable(True)
+        ms_v = time_calls(dm3, lambda: dm3.deform_batched_raw(ni, d_w3.ptr, d_pal3.ptr, d_v32.ptr, None, api.OUT_VERTEX32,
+                                                              flags_dev | api.WEIGHTS_SHARED, 0.1), 20)
+        ncalls, skin_ms, _m = dm3.profile_collect()
+        dm3.profile_enable(False)
+        bv = static + model3.nv * 8 + model3.nv * 12 + ni * (model3.nv * 32 + model3.nb * 48)
+        out["config3_vertex32_output"] = {"ms_per_call": ms_v, "vertices_per_s": ni * model3.nv / (ms_v * 1e-3),
+                                          "deform_kernel_ms": skin_ms / ncalls,
+                                          "algorithmic_GBs": bv / (skin_ms / ncalls * 1e-3) / 1e9,
+                                          "frac_of_8TBs": bv / (skin_ms / ncalls * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "placement": _pl}
+        for b in (d_w3, d_pal3, d_v32):
+            b.free()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["config3_vertex32_output"] = {"error": repr(e)}
+
     # config 3' (SURVEY 8d): the same 1024-instance crowd with PER-INSTANCE morph weights (every instance its
     # own facial state): the fused gather path, 4 instances per pass over a vertex's morph row.
     try:
