@@ -497,3 +497,29 @@ def test_gpu_bone_morphs_vs_oracle(oracle, nb, seed, n_ik, n_app):
     sk.solve_device(70, d_pose.ptr, d_out.ptr, None, d_w.ptr)
     api.check(api.lib().mmdx_device_synchronize())
     gu.assert_bits_equal(d_out.download((70, nb, 16), np.float32), got, "device-resident call")
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_crowd_rig(oracle):
+    """BASELINE config-3 dimensions for the palette producer: 1024 instances x 300 bones, a 6000-key motion with
+    ~16k distinct curve tables, every instance at its own frame.  Poses of 48 sampled instances and ALL 1024
+    palettes (FK rig and IK rig) against the oracle."""
+    ni, nb = 1024, 300
+    names = [f"b{i}" for i in range(nb)]
+    v = vmd.Vmd(vmd.write_vmd(synth.make_bone_keys(names, 303, keys_per=20, span=600), []))
+    frames = ((np.arange(ni) * 7) % 600).astype(np.uint32)
+    poses = v.bind_bones(names).eval(frames)
+    sample = np.r_[0:16, 500:516, ni - 16:ni]
+    gu.assert_bits_equal(poses[sample], oracle_poses(oracle, v, names, frames[sample]), "sampled poses")
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, 3003, n_ik=8, n_append=12, post_physics=0.0, levels=1)
+    fk = vmd.Skeleton(rest, parent).solve(poses)
+    iksk = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik)
+    assert iksk.info["solver"] == vmd.SOLVER_SERIAL
+    ikp = iksk.solve(poses)
+    n_nan = 0
+    for i in range(ni):
+        gu.assert_bits_equal(fk[i], oracle.bone_solve(rest, parent, poses[i]), f"FK palette of instance {i}")
+        want = oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, ik)
+        gu.assert_bits_equal_or_both_nan(ikp[i], want, f"IK palette of instance {i}")
+        n_nan += int(np.isnan(want).any())
+    assert n_nan < ni // 4                               # degenerate chains (NaN upstream too) stay the exception
