@@ -22,6 +22,10 @@ __global__ __launch_bounds__(kThreads) void pattern_fill(float4 *a, float4 *b, u
         }
     }
 }
+__global__ __launch_bounds__(kThreads) void fill(float4 *d, size_t n) {
+    const size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < n) d[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
 float run(void *a, void *b, size_t pitch_bytes) {
     const uint32_t nv = 50000, ni = 1024, ntiles = (nv + kTile - 1) / kTile, ngroups = ni / 16;
     hipEvent_t e0, e1;
@@ -39,10 +43,16 @@ int main() {
     const size_t row = 600000;
     const std::vector<size_t> extra = {0, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 55360 /* 640 KiB */, 65536, 131072, 448576 /* 1 MiB */};
     const size_t maxpitch = row + 448576;
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < 6; ++t) {
         void *a, *b;
         CK(hipMalloc(&a, maxpitch * 1024 + (2 << 20))); CK(hipMalloc(&b, maxpitch * 1024 + (2 << 20)));
-        std::printf("placement %d:", t);
+        if (t >= 2) {   // does touching the arrays with a linear fill first change anything?
+            const size_t n = (maxpitch * 1024) / 16;
+            fill<<<uint32_t((n + kThreads - 1) / kThreads), kThreads>>>((float4 *)a, n);
+            fill<<<uint32_t((n + kThreads - 1) / kThreads), kThreads>>>((float4 *)b, n);
+            CK(hipDeviceSynchronize());
+        }
+        std::printf("placement %d%s:", t, t >= 2 ? " (pre-filled)" : "");
         for (size_t x : extra) std::printf(" +%zu:%5.0f", x, run(a, b, row + x));
         std::printf("\n");
         CK(hipFree(a)); CK(hipFree(b));
