@@ -523,3 +523,37 @@ def test_gpu_full_size_crowd_rig(oracle):
         gu.assert_bits_equal_or_both_nan(ikp[i], want, f"IK palette of instance {i}")
         n_nan += int(np.isnan(want).any())
     assert n_nan < ni // 4                               # degenerate chains (NaN upstream too) stay the exception
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_links", [1, 6, 7, 12])
+def test_gpu_long_ik_chains(oracle, n_links):
+    """A 200-bone line with one IK bone at its end: chains of up to 6 links run on the solver's LDS window,
+    longer ones on the HBM scratch state -- both sides of that boundary against the oracle."""
+    nb = 200
+    rest = np.stack([np.zeros(nb), np.arange(nb) * 0.1, np.zeros(nb)], 1).astype(np.float32)
+    parent = np.arange(-1, nb - 1).astype(np.int32)
+    parent[nb - 1] = 0
+    flags = np.zeros(nb, np.uint16)
+    flags[nb - 1] = 0x20
+    rest[nb - 1] = rest[nb - 2] + np.float32(0.05)
+    tgt = nb - 2
+    links = list(range(tgt - 1, tgt - 1 - n_links, -1))
+    ik = dict(target=np.full(nb, -1, np.int32), loop=np.zeros(nb, np.int32), angle=np.zeros(nb, np.float32),
+              link_off=np.zeros(nb + 1, np.uint32), link_bone=np.asarray(links, np.int32),
+              link_limited=np.zeros(n_links, np.uint8), link_lo=np.zeros((n_links, 3), np.float32),
+              link_hi=np.zeros((n_links, 3), np.float32))
+    ik["target"][nb - 1], ik["loop"][nb - 1], ik["angle"][nb - 1] = tgt, 12, 1.0
+    ik["link_off"][nb:] = n_links
+    sk = vmd.Skeleton(rest, parent, None, flags, None, None, ik)
+    rng = np.random.RandomState(n_links)
+    poses = np.zeros((70, nb, 8), np.float32)
+    poses[..., 7] = 1
+    poses[:, nb - 1, 0:3] = rng.uniform(-1, 1, (70, 3))
+    got = sk.solve(poses)
+    moved = 0
+    for i in range(70):
+        want = oracle.bone_solve_full(rest, parent, poses[i], None, flags, None, None, ik)
+        gu.assert_bits_equal_or_both_nan(got[i], want, f"instance {i}")
+        moved += int(not np.array_equal(want, oracle.bone_solve(rest, parent, poses[i])))
+    assert moved > 60                                    # the chains really bend
