@@ -48,15 +48,27 @@ def up_to_date() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and up_to_date():
         return LIB
-    cmd = [hipcc()] + flags() + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed")
-    if verbose and r.stderr:
-        sys.stderr.write(r.stderr)
+    # Several ranks of one job may get here at once (bench.py --gpus N on a fresh copy of the tree whose
+    # timestamps make the library look stale): one of them builds, into a temporary file that is renamed over
+    # the library in one step, the others wait on the lock and find it up to date.
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and up_to_date():
+            return LIB
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [hipcc()] + flags() + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("hipcc failed")
+        if verbose and r.stderr:
+            sys.stderr.write(r.stderr)
+        os.replace(tmp, LIB)
     return LIB
 
 
