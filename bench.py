@@ -405,16 +405,26 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
                       "cpu_reference_palettes_per_s": ni * model3.nb / secs})
             rmot.close(); rsk.close()
         out["config3_motion_to_palettes"] = c
-        # the same crowd on a rig with CCD-IK chains and append bones: the serial per-instance solver
+        # the same crowd on a rig with CCD-IK chains and append bones: the ordered solver (the reference's
+        # evaluation sequence cut into rounds of independent bones / IK solves).  One of the 8 chains asks for
+        # 300 iterations (clamped to the reference's 256) over 3 limited links: that chain alone is the
+        # critical path.  Also the rig with the append bones only.
         rig = synth.make_ik_rig(model3.nb, 3003, n_ik=8, n_append=12, post_physics=0.0, levels=1)
         ski = vmdmod.Skeleton(*rig)
+        ska = vmdmod.Skeleton(rig[0], rig[1], rig[2], (np.asarray(rig[3]) & ~np.uint16(0x20)).astype(np.uint16), rig[4], rig[5])
+        ms_a = time_calls(dm3, lambda: (bm.eval_device(ni, d_fr.ptr, d_pose.ptr, dm3),
+                                        ska.solve_device(ni, d_pose.ptr, d_pal.ptr, dm3)), 20)
+        out["config3_append_rig_palettes"] = {"instances": ni, "bones": model3.nb, "append_bones": ska.info["n_append_bones"],
+                                              "solve_rounds": ska.info["n_solve_rounds"], "gpu_ms_poses_plus_palettes": ms_a,
+                                              "gpu_palettes_per_s": ni * model3.nb / (ms_a * 1e-3)}
 
         def producer_ik():
             bm.eval_device(ni, d_fr.ptr, d_pose.ptr, dm3)
             ski.solve_device(ni, d_pose.ptr, d_pal.ptr, dm3)
         ms_i = time_calls(dm3, producer_ik, 10)
         ci = {"instances": ni, "bones": model3.nb, "ik_chains": ski.info["n_ik_bones"], "ik_links": ski.info["n_ik_links"],
-              "append_bones": ski.info["n_append_bones"], "gpu_ms_poses_plus_palettes": ms_i,
+              "append_bones": ski.info["n_append_bones"], "solve_rounds": ski.info["n_solve_rounds"],
+              "gpu_ms_poses_plus_palettes": ms_i,
               "gpu_palettes_per_s": ni * model3.nb / (ms_i * 1e-3)}
         if reference_available():
             rmot = ReferenceMotion(path)

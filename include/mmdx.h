@@ -427,12 +427,15 @@ typedef struct mmdx_skeleton_info {
     uint32_t solver;                          /* MMDX_SOLVER_*                                        */
     uint32_t n_ik_bones, n_ik_links, n_append_bones;
     uint32_t n_bone_morph_entries;            /* applications of a bone-morph entry (groups expanded)  */
+    uint32_t n_solve_rounds;                  /* ordered solver: rounds the evaluation sequence was cut
+                                                 into (independent bones share a round), else 0         */
 } mmdx_skeleton_info;
 
 enum {
     MMDX_SOLVER_PARALLEL_FK = 0,  /* no IK / append: one thread per (instance, bone), bit-exact      */
-    MMDX_SOLVER_SERIAL = 1        /* IK / append present: the reference's in-order sweep, one thread
-                                     per instance; sin/cos/asin/acos/atan2 through the device's double
+    MMDX_SOLVER_SERIAL = 1        /* IK / append present: the reference's evaluation sequence; bones
+                                     (and IK solves) that touch disjoint state run side by side, the
+                                     rest in order; sin/cos/asin/acos/atan2 through the device's double
                                      libm like the reference's through the host's     */
 };
 

@@ -416,12 +416,30 @@ typedef struct {
 enum { FIX_NONE = 0, FIX_X, FIX_Y, FIX_Z, FIX_ALL };
 enum { ORDER_ZXY = 0, ORDER_XYZ, ORDER_YZX };
 
-static float f_sqrt(float x) { return (float)sqrt((double)x); }
-static float f_sin(float x) { return (float)sin((double)x); }
-static float f_cos(float x) { return (float)cos((double)x); }
-static float f_asin(float x) { return (float)asin((double)x); }
-static float f_acos(float x) { return (float)acos((double)x); }
-static float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+/* Optional trace of the transcendental calls of the bone solve (tools/rig_mismatch_probe.py re-evaluates them on
+ * the device to tell a libm difference from anything else): records of 4 words -- function (0 sqrt, 1 sin, 2 cos,
+ * 3 asin, 4 acos, 5 atan2), argument bits, second argument bits, result bits.  Not thread-safe; off by default. */
+static uint32_t *g_trace;
+static size_t g_trace_cap, g_trace_n;
+void mmdx_oracle_trace_libm(uint32_t *records, size_t capacity) { g_trace = records; g_trace_cap = capacity; g_trace_n = 0; }
+size_t mmdx_oracle_trace_count(void) { return g_trace_n; }
+static float traced(uint32_t fn, float a, float b, float r) {
+    if (g_trace) {
+        if (g_trace_n < g_trace_cap) {
+            uint32_t *rec = g_trace + 4 * g_trace_n;
+            rec[0] = fn;
+            memcpy(rec + 1, &a, 4); memcpy(rec + 2, &b, 4); memcpy(rec + 3, &r, 4);
+        }
+        ++g_trace_n;
+    }
+    return r;
+}
+static float f_sqrt(float x) { return traced(0, x, 0.0f, (float)sqrt((double)x)); }
+static float f_sin(float x) { return traced(1, x, 0.0f, (float)sin((double)x)); }
+static float f_cos(float x) { return traced(2, x, 0.0f, (float)cos((double)x)); }
+static float f_asin(float x) { return traced(3, x, 0.0f, (float)asin((double)x)); }
+static float f_acos(float x) { return traced(4, x, 0.0f, (float)acos((double)x)); }
+static float f_atan2(float y, float x) { return traced(5, y, x, (float)atan2((double)y, (double)x)); }
 
 static quat_t q_identity(void) { quat_t q = {0.0f, 0.0f, 0.0f, 1.0f}; return q; }
 static quat_t q_mul(quat_t a, quat_t q) {                  /* L/util/math_impl.inl:510-517 */

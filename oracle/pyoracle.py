@@ -169,6 +169,21 @@ class Oracle:
             raise ValueError("oracle bone solve: nested IK or an index out of range")
         return out
 
+    def trace_libm(self, fn, capacity=1 << 22):
+        """Run fn() with the bone solve's transcendental calls recorded; returns u32 [N,4] records (function id,
+        argument bits, second argument bits, result bits) -- see mmdx_oracle_trace_libm."""
+        buf = np.zeros((capacity, 4), np.uint32)
+        self.lib.mmdx_oracle_trace_count.restype = C.c_size_t
+        self.lib.mmdx_oracle_trace_libm(buf.ctypes.data_as(C.c_void_p), C.c_size_t(capacity))
+        try:
+            fn()
+            n = int(self.lib.mmdx_oracle_trace_count())
+        finally:
+            self.lib.mmdx_oracle_trace_libm(None, C.c_size_t(0))
+        if n > capacity:
+            raise ValueError("libm trace overflow: %d calls" % n)
+        return buf[:n].copy()
+
     def time_crowd(self, model, rates, palettes, normalize=True):
         """Seconds for one crowd step (shared morph pass + one skinning pass per palette)."""
         t, ids, w = self.normalize(model) if normalize else (

@@ -31,6 +31,8 @@ def hipcc() -> str:
 
 def flags() -> list[str]:
     extra = ["-DMMDX_ABLATE"] if os.environ.get("MMDX_BUILD_ABLATE") else []   # tools/ experiments only
+    if os.environ.get("MMDX_BUILD_DEFS"):
+        extra += ["-D" + d for d in os.environ["MMDX_BUILD_DEFS"].split(",")]
     if os.environ.get("MMDX_BUILD_TILE"):
         extra.append("-DMMDX_TILE=" + os.environ["MMDX_BUILD_TILE"])
     return extra + [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",

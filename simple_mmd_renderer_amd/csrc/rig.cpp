@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -89,6 +90,113 @@ void build_bone_motion(const std::vector<std::string> &track_names, const std::v
         out.key_off.push_back(uint32_t(out.key_frame.size()));
     }
 }
+
+void solve_event_sets(const SkeletonPlan &plan, uint32_t bone, std::vector<uint32_t> &reads, std::vector<uint32_t> &writes) {
+    reads.clear();
+    writes.clear();
+    // one bone's transform (rig_kernels.hip transform_at): reads the parent's local matrix and, for an append
+    // bone, the append parent's totals; writes every field of its own state
+    auto transform = [&](uint32_t x) {
+        const BoneRec &r = plan.bones[x];
+        if (r.parent >= 0) reads.push_back(uint32_t(r.parent));
+        if (r.bits & (kBoneAppendRot | kBoneAppendTr)) reads.push_back(uint32_t(r.append_parent));
+        writes.push_back(x);
+    };
+    transform(bone);
+    if (plan.bones[bone].bits & kBoneHasIk) {                 // the CCD loop re-transforms its links and target
+        const IkRec &ik = plan.iks[plan.bones[bone].ik];
+        for (uint32_t j = 0; j < ik.nlinks; ++j) transform(plan.links[ik.link0 + j].bone);
+        transform(ik.target);
+    }
+}
+
+namespace {
+
+// Cut the evaluation sequence into rounds.  An event depends on every earlier event that wrote a bone it
+// reads or writes, or read a bone it writes; list scheduling over that graph, with two rules that keep the
+// expensive events together: bone evaluations without IK go first whenever one is ready, and IK solves are
+// issued only when nothing else is -- so independent chains (left / right leg ...) share a round instead of
+// each paying a round of its own.  The two lists (pre- / post-physics) are scheduled separately: the
+// skinning matrices of the first are written out in between.
+void schedule_rounds(SkeletonPlan &pl) {
+    pl.windows = 0;
+    if (pl.n_fast) {
+        const size_t per_window = size_t(kSolveInstances) * (pl.fast_slots * kSerialStateFloats + 1) * sizeof(float);
+        pl.windows = uint32_t(std::min<size_t>({size_t(kSolveSlots), size_t(pl.n_fast), std::max<size_t>(kSolveLdsBudget / per_window, 1)}));
+    }
+    std::vector<uint32_t> reads, writes;
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+        const uint32_t s0 = pass ? pl.n_pre : 0, n = pass ? pl.nb - pl.n_pre : pl.n_pre;
+        std::vector<std::vector<uint32_t>> succ(n);
+        std::vector<uint32_t> indeg(n, 0);
+        std::vector<int64_t> last_writer(pl.nb, -1);
+        std::vector<std::vector<uint32_t>> readers(pl.nb);      // since the last write
+        std::vector<uint32_t> deps;
+        for (uint32_t e = 0; e < n; ++e) {
+            solve_event_sets(pl, pl.order[s0 + e], reads, writes);
+            deps.clear();
+            for (uint32_t x : reads) if (last_writer[x] >= 0) deps.push_back(uint32_t(last_writer[x]));
+            for (uint32_t x : writes) {
+                if (last_writer[x] >= 0) deps.push_back(uint32_t(last_writer[x]));
+                deps.insert(deps.end(), readers[x].begin(), readers[x].end());
+            }
+            std::sort(deps.begin(), deps.end());
+            deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+            for (uint32_t dep : deps) {
+                if (dep == e) continue;
+                succ[dep].push_back(e);
+                ++indeg[e];
+            }
+            for (uint32_t x : writes) { last_writer[x] = e; readers[x].clear(); }
+            for (uint32_t x : reads) if (last_writer[x] != int64_t(e)) readers[x].push_back(e);
+        }
+        // ready lists, each kept in sequence order: 0 = no IK, 1 = IK on the HBM state, 2 = IK on an LDS window
+        std::vector<uint32_t> ready[3], round;
+        auto kind = [&](uint32_t e) -> int {
+            const BoneRec &r = pl.bones[pl.order[s0 + e]];
+            return (r.bits & kBoneHasIk) ? (pl.iks[r.ik].fast ? 2 : 1) : 0;
+        };
+        for (uint32_t e = 0; e < n; ++e) if (!indeg[e]) ready[kind(e)].push_back(e);
+        auto take = [&](int k, size_t limit) {
+            auto &q = ready[k];
+            const size_t c = std::min(q.size(), limit);
+            round.insert(round.end(), q.begin(), q.begin() + c);
+            q.erase(q.begin(), q.begin() + c);
+        };
+        // MMDX_SOLVE_SEQUENTIAL=1: one event per round in sequence order (debugging aid: A/B against the schedule)
+        const char *seq_env = std::getenv("MMDX_SOLVE_SEQUENTIAL");
+        if (seq_env && seq_env[0] == '1') {
+            for (uint32_t e = 0; e < n; ++e) {
+                pl.rounds.push_back({uint32_t(pl.events.size()), 1u});
+                pl.events.push_back(pl.order[s0 + e]);
+            }
+            if (!pass) pl.n_rounds_pre = uint32_t(pl.rounds.size());
+            continue;
+        }
+        uint32_t done = 0;
+        while (done < n) {
+            round.clear();
+            if (!ready[0].empty()) {
+                take(0, kSolveSlots);
+            } else {
+                take(2, pl.windows);                          // the window owners sit in the first slots
+                take(1, kSolveSlots - round.size());
+            }
+            pl.rounds.push_back({uint32_t(pl.events.size()), uint32_t(round.size())});
+            for (uint32_t e : round) pl.events.push_back(pl.order[s0 + e]);
+            done += uint32_t(round.size());
+            for (uint32_t e : round)
+                for (uint32_t nx : succ[e])
+                    if (--indeg[nx] == 0) {
+                        auto &q = ready[kind(nx)];
+                        q.insert(std::upper_bound(q.begin(), q.end(), nx), nx);
+                    }
+        }
+        if (!pass) pl.n_rounds_pre = uint32_t(pl.rounds.size());
+    }
+}
+
+}  // namespace
 
 mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::string &err) {
     out = SkeletonPlan();
@@ -202,7 +310,7 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
         return MMDX_OK;
     }
 
-    // ---- serial solver tables (Poser ctor, L/motion/poser_impl.inl:29-97) -----------------------
+    // ---- ordered solver tables (Poser ctor, L/motion/poser_impl.inl:29-97) -----------------------
     out.bones.resize(nb);
     for (uint32_t b = 0; b < nb; ++b) {
         BoneRec &r = out.bones[b];
@@ -300,6 +408,7 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
     }
     out.n_ik = uint32_t(out.iks.size());
     out.n_links = uint32_t(out.links.size());
+    schedule_rounds(out);
     return MMDX_OK;
 }
 

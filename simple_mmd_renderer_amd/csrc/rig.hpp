@@ -49,7 +49,7 @@ enum : uint32_t { kBoneAppendRot = 1u, kBoneAppendTr = 2u, kBoneIsIkLink = 4u, k
 enum : uint32_t { kFixNone = 0, kFixX = 1, kFixY = 2, kFixZ = 3, kFixAll = 4 };
 enum : uint32_t { kOrderZXY = 0, kOrderXYZ = 1, kOrderYZX = 2 };
 
-struct BoneRec {                                // serial solver: everything static about one bone (48 B)
+struct BoneRec {                                // ordered solver: everything static about one bone (48 B)
     float local_offset[3];
     int32_t parent;                             // -1 = none
     float neg_rest[3];
@@ -66,7 +66,7 @@ struct IkRec {
     int32_t outside_parent;                     // fast: parent bone of the root-most link, -1 = none
     uint32_t pad;
 };
-constexpr uint32_t kMaxFastLinks = 6;           // (links + target + outside parent) x 31 x 64 floats <= 64 KiB
+constexpr uint32_t kMaxFastLinks = 6;           // window = (links + target + outside parent) x 31 floats per lane
 struct LinkRec {                                // the per-link constants the Poser ctor derives (48 B)
     uint32_t bone, limited, order, fix;
     float lo[4], hi[4];                         // min / max per component, [3] unused
@@ -80,24 +80,42 @@ struct BoneMorphApp {                           // one application of a bone-mor
     float rot[4];
 };
 
+// Schedule of the ordered solver: the evaluation sequence cut into rounds of events (bone evaluations, an
+// IK bone's including its CCD solve) that touch disjoint state, so the slots of one instance run a round
+// concurrently and the result is the serial sequence's.  Chains solved on the LDS window sit in the first
+// `windows` slots of their round.
+struct RoundRec {
+    uint32_t first, count;                      // events[first .. first + count), count <= kSolveSlots
+};
+constexpr uint32_t kSolveSlots = 16;            // events of one instance in flight
+constexpr uint32_t kSolveInstances = 16;        // instances per workgroup (kSolveSlots x kSolveInstances threads)
+constexpr size_t kSolveLdsBudget = 96 * 1024;   // LDS windows of one workgroup
+
 struct SkeletonPlan {
     uint32_t nb = 0, n_pre = 0, n_post = 0, max_chain = 0;
     uint32_t nm = 0;                            // morphs of the model (row length of the rates)
     std::vector<BoneMorphApp> apps;             // bone-morph applications in UpdateMorphTransform order
     std::vector<float> app_chain;               // group sub-rates
     uint32_t n_ik = 0, n_links = 0, n_append = 0, fast_slots = 0, n_fast = 0;
-    bool serial = false;                        // IK or append bones present: not a pure parent-chain FK
+    bool serial = false;                        // IK or append bones present: the ordered solver, not parallel FK
     std::vector<uint32_t> order;                // evaluation sequence: pre-physics sorted, then post-physics sorted
     // parallel FK
     std::vector<float> local_offset;            // [nb][4] rest position relative to the parent (or absolute)
     std::vector<float> neg_rest;                // [nb][4] -rest position: translation row of the global offset
     std::vector<uint32_t> chain_off;            // [nb+1]
     std::vector<uint32_t> chain;                // per bone: kIdentityParent? then ancestors root-first, the bone last
-    // serial solver
+    // ordered solver
     std::vector<BoneRec> bones;
     std::vector<IkRec> iks;
     std::vector<LinkRec> links;
+    std::vector<uint32_t> events;               // bone ids, round after round
+    std::vector<RoundRec> rounds;               // pre-physics rounds, then post-physics rounds
+    uint32_t n_rounds_pre = 0, windows = 0;     // windows: LDS chain windows per instance
 };
+
+// Bones whose state evaluating `bone` reads / writes in the ordered solver (UpdateBoneTransform incl. the IK
+// solve): what the round schedule is derived from, exposed for the schedule checker in tests/.
+void solve_event_sets(const SkeletonPlan &plan, uint32_t bone, std::vector<uint32_t> &reads, std::vector<uint32_t> &writes);
 
 // status: MMDX_OK, or the error code with its text in `err`.
 mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::string &err);
@@ -132,8 +150,12 @@ struct SerialParams {
     const BoneRec *bones;
     const IkRec *iks;
     const LinkRec *links;
+    const uint32_t *events;
+    const RoundRec *rounds;
     uint32_t nb, ni, n_pre;
+    uint32_t n_rounds_pre, n_rounds;
     uint32_t fast_slots;                        // LDS window size in bones (0: no fast chain)
+    uint32_t windows;                           // LDS windows per instance
 };
 
 }  // namespace mmdx

@@ -60,10 +60,11 @@ struct mmdx_skeleton_s {
     SkeletonPlan plan;
     int device = -1;
     Buf local_offset, neg_rest, chain_off, chain, poses_in, out;
-    Buf order, bones, iks, links, state;                  // serial solver
+    Buf order, bones, iks, links, events, rounds, state;  // ordered solver
     Buf apps, app_chain, rates_in, morph_state;           // bone morphs
     void release_all() {
-        for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &state,
+        for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &events, &rounds,
+                       &state,
                        &apps, &app_chain, &rates_in, &morph_state})
             b->release();
     }
@@ -184,6 +185,7 @@ mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t s, mmdx_skeleton_info *info) 
     info->n_ik_links = s->plan.n_links;
     info->n_append_bones = s->plan.n_append;
     info->n_bone_morph_entries = uint32_t(s->plan.apps.size());
+    info->n_solve_rounds = uint32_t(s->plan.rounds.size());
     return MMDX_OK;
 }
 
@@ -210,6 +212,8 @@ mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, u
             HIP_TRY(s->bones.upload(pl.bones));
             HIP_TRY(s->iks.upload(pl.iks));
             HIP_TRY(s->links.upload(pl.links));
+            HIP_TRY(s->events.upload(pl.events));
+            HIP_TRY(s->rounds.upload(pl.rounds));
         } else {
             HIP_TRY(s->local_offset.upload(pl.local_offset));
             HIP_TRY(s->neg_rest.upload(pl.neg_rest));
@@ -267,9 +271,13 @@ mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, u
         sp.bones = static_cast<const BoneRec *>(s->bones.ptr);
         sp.iks = static_cast<const IkRec *>(s->iks.ptr);
         sp.links = static_cast<const LinkRec *>(s->links.ptr);
+        sp.events = static_cast<const uint32_t *>(s->events.ptr);
+        sp.rounds = static_cast<const RoundRec *>(s->rounds.ptr);
         sp.nb = pl.nb; sp.ni = n_instances; sp.n_pre = pl.n_pre;
+        sp.n_rounds_pre = pl.n_rounds_pre; sp.n_rounds = uint32_t(pl.rounds.size());
         sp.fast_slots = pl.fast_slots;
-        HIP_TRY(launch_skeleton_serial(sp, st));
+        sp.windows = pl.windows;
+        HIP_TRY(launch_skeleton_ordered(sp, st));
     } else {
         SkeletonParams fp;
         fp.morph = morph_state;

@@ -173,26 +173,30 @@ __global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const Skeleton
     for (int y = 0; y < 4; ++y) out[y] = make_float4(S.m[y][0], S.m[y][1], S.m[y][2], S.m[y][3]);
 }
 
-// ---- serial solver: append (inherit) bones + CCD-IK ------------------------------------------------
-// One thread per instance walks the reference's evaluation sequence (Poser::UpdateBoneTransform,
-// L/motion/poser_impl.inl:142-310) with the per-bone state in HBM scratch laid out [bone][field][instance]
-// (lanes = consecutive instances, so every state access of a wave is one coalesced line).  Bones, IK
-// chains and links are the same for all lanes: those records come through scalar loads.  The float
+// ---- ordered solver: append (inherit) bones + CCD-IK -----------------------------------------------
+// The reference's evaluation sequence (Poser::UpdateBoneTransform, L/motion/poser_impl.inl:142-310) with the
+// per-bone state in HBM scratch laid out [bone][field][instance] (lanes = consecutive instances).  The float
 // operation order is the reference's; sqrt/sin/cos/asin/acos/atan2 go through double and back like
-// L/util/math.inl:27-45.
-constexpr uint32_t kSerialThreads = 64;
+// L/util/math.inl:27-45.  skeleton_ordered_kernel below runs the sequence; bone_morph_kernel (one thread
+// per instance) prepares the bone morphs' contribution.
+constexpr uint32_t kBoneMorphThreads = 64;
 
 struct Quat {
     float i, j, k, e;
 };
 enum : uint32_t { kStTotalRot = 0, kStIkRot = 4, kStPreIkRot = 8, kStTotalTr = 12, kStLocal = 15 };
 
-template <typename Ptr>
+// floats of one lane's LDS window: fast_slots cells, padded to an odd count so the lanes of a wave fall into
+// different banks
+__host__ __device__ constexpr uint32_t window_floats(uint32_t fast_slots) { return (fast_slots * kSerialStateFloats) | 1u; }
+
+template <typename Ptr, bool kCellMajor>
 struct StateT {
-    Ptr base;         // already offset to this lane (global scratch: + instance; LDS window: + lane)
-    size_t stride;    // elements between consecutive (index, field) cells: instances in HBM, 64 lanes in LDS
+    Ptr base;         // already offset to this lane (global scratch: + instance; LDS window: the lane's own cells)
+    size_t stride;    // HBM scratch: elements between consecutive (index, field) cells = instances
     __device__ __forceinline__ auto &at(uint32_t idx, uint32_t f) const {
-        return base[(size_t(idx) * kSerialStateFloats + f) * stride];
+        if constexpr (kCellMajor) return base[idx * kSerialStateFloats + f];   // field = immediate offset
+        else return base[(size_t(idx) * kSerialStateFloats + f) * stride];
     }
     __device__ __forceinline__ Quat quat(uint32_t idx, uint32_t f) const {
         return {at(idx, f), at(idx, f + 1), at(idx, f + 2), at(idx, f + 3)};
@@ -211,12 +215,21 @@ struct StateT {
         for (int k = 0; k < 16; ++k) at(idx, kStLocal + k) = m.m[k / 4][k % 4];
     }
 };
-using State = StateT<float *>;                                             // per-bone state in HBM scratch
-using ChainState = StateT<__attribute__((address_space(3))) float *>;      // one IK chain's bones in LDS
+using State = StateT<float *, false>;                                       // per-bone state in HBM scratch
+using ChainState = StateT<__attribute__((address_space(3))) float *, true>;  // one IK chain's bones in LDS, a lane's
+                                                                             // cells contiguous
 
-__device__ __forceinline__ float d_sqrt(float x) { return float(sqrt(double(x))); }
+// float(sqrt(double(x))) is the correctly rounded f32 square root (rounding twice is innocuous for sqrt when the
+// wide format has >= 2 x 24 + 2 bits), which is what sqrtf compiles to; sincos shares its argument reduction and
+// polynomials with sin and cos.  Both substitutions checked over all 2^32 floats: tools/libm_probe.hip.
+__device__ __forceinline__ float d_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ void d_sincos(float x, float *s, float *c) {
+    double ds, dc;
+    sincos(double(x), &ds, &dc);
+    *s = float(ds);
+    *c = float(dc);
+}
 __device__ __forceinline__ float d_sin(float x) { return float(sin(double(x))); }
-__device__ __forceinline__ float d_cos(float x) { return float(cos(double(x))); }
 __device__ __forceinline__ float d_asin(float x) { return float(asin(double(x))); }
 __device__ __forceinline__ float d_acos(float x) { return float(acos(double(x))); }
 __device__ __forceinline__ float d_atan2(float y, float x) { return float(atan2(double(y), double(x))); }
@@ -274,43 +287,45 @@ __device__ Quat axis_to_quat(const V3 axis, float angle) {             // :1047-
     const float norm = d_sqrt(axis.x * axis.x + axis.y * axis.y + axis.z * axis.z);
     if (norm < 1e-7f) return q_identity();
     angle *= 0.5f;
-    const float s = d_sin(angle) / norm;
-    return {s * axis.x, s * axis.y, s * axis.z, d_cos(angle)};
+    float sn, cs;
+    d_sincos(angle, &sn, &cs);
+    const float s = sn / norm;
+    return {s * axis.x, s * axis.y, s * axis.z, cs};
 }
 
-__device__ void quat_to_euler(uint32_t order, const Quat q, float *r) {   // :1059-1071, :1110-1135
+// The three Euler orders share one shape -- one asin and two atan2 of products of the quaternion's components --
+// so the operands are selected per order and each function is called once: lanes of a wave that solve chains
+// with different orders then do not take turns through three copies of the double-precision calls.
+__device__ __forceinline__ void quat_to_euler(uint32_t order, const Quat q, float *r) {   // :1059-1071, :1110-1135
     const float ii = q.i * q.i, jj = q.j * q.j, kk = q.k * q.k;
     const float ei = q.e * q.i, ej = q.e * q.j, ek = q.e * q.k;
     const float ij = q.i * q.j, ik = q.i * q.k, jk = q.j * q.k;
-    if (order == kOrderZXY) {
-        r[0] = d_asin(2.0f * (ei + jk));
-        r[1] = d_atan2(2.0f * (ej - ik), 1 - 2.0f * (ii + jj));
-        r[2] = d_atan2(2.0f * (ek - ij), 1 - 2.0f * (ii + kk));
-    } else if (order == kOrderXYZ) {
-        r[0] = d_atan2(2.0f * (ei - jk), 1 - 2.0f * (ii + jj));
-        r[1] = d_asin(2.0f * (ej + ik));
-        r[2] = d_atan2(2.0f * (ek - ij), 1 - 2.0f * (jj + kk));
-    } else {
-        r[0] = d_atan2(2.0f * (ei - jk), 1 - 2.0f * (ii + kk));
-        r[1] = d_atan2(2.0f * (ej - ik), 1 - 2.0f * (jj + kk));
-        r[2] = d_asin(2.0f * (ek + ij));
-    }
+    const bool zxy = order == kOrderZXY, xyz = order == kOrderXYZ;
+    // component 0: ZXY asin(2(ei + jk)); XYZ atan2(2(ei - jk), 1 - 2(ii + jj)); YZX atan2(2(ei - jk), 1 - 2(ii + kk))
+    // component 1: ZXY atan2(2(ej - ik), 1 - 2(ii + jj)); XYZ asin(2(ej + ik)); YZX atan2(2(ej - ik), 1 - 2(jj + kk))
+    // component 2: ZXY atan2(2(ek - ij), 1 - 2(ii + kk)); XYZ atan2(2(ek - ij), 1 - 2(jj + kk)); YZX asin(2(ek + ij))
+    const float s_arg = zxy ? 2.0f * (ei + jk) : xyz ? 2.0f * (ej + ik) : 2.0f * (ek + ij);
+    const float a_y = zxy ? 2.0f * (ej - ik) : 2.0f * (ei - jk);               // first atan2: component 1 (ZXY) or 0
+    const float a_x = zxy ? 1 - 2.0f * (ii + jj) : xyz ? 1 - 2.0f * (ii + jj) : 1 - 2.0f * (ii + kk);
+    const float b_y = (zxy || xyz) ? 2.0f * (ek - ij) : 2.0f * (ej - ik);       // second atan2: component 2 or 1 (YZX)
+    const float b_x = zxy ? 1 - 2.0f * (ii + kk) : 1 - 2.0f * (jj + kk);
+    const float s = d_asin(s_arg), a = d_atan2(a_y, a_x), b = d_atan2(b_y, b_x);
+    r[0] = zxy ? s : a;
+    r[1] = zxy ? a : xyz ? s : b;
+    r[2] = zxy ? b : xyz ? b : s;
 }
-__device__ Quat euler_to_quat(uint32_t order, const float *r) {           // :1137-1149, :1176-1201
-    const float cx = d_cos(r[0] * 0.5f), sx = d_sin(r[0] * 0.5f);
-    const float cy = d_cos(r[1] * 0.5f), sy = d_sin(r[1] * 0.5f);
-    const float cz = d_cos(r[2] * 0.5f), sz = d_sin(r[2] * 0.5f);
+__device__ __forceinline__ Quat euler_to_quat(uint32_t order, const float *r) {           // :1137-1149, :1176-1201
+    float cx, sx, cy, sy, cz, sz;
+    d_sincos(r[0] * 0.5f, &sx, &cx);
+    d_sincos(r[1] * 0.5f, &sy, &cy);
+    d_sincos(r[2] * 0.5f, &sz, &cz);
+    // every component is (product of three) +- (product of three): the orders differ in the signs only
+    const float ia = sx * cy * cz, ib = cx * sy * sz, ja = cx * sy * cz, jb = sx * cy * sz, ka = cx * cy * sz, kb = sx * sy * cz;
     Quat q;
-    if (order == kOrderZXY) {
-        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz - cx * sy * sz;
-        q.j = cx * sy * cz + sx * cy * sz; q.k = cx * cy * sz + sx * sy * cz;
-    } else if (order == kOrderXYZ) {
-        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz + cx * sy * sz;
-        q.j = cx * sy * cz - sx * cy * sz; q.k = sx * sy * cz + cx * cy * sz;
-    } else {
-        q.e = cx * cy * cz - sx * sy * sz; q.i = sx * cy * cz + cx * sy * sz;
-        q.j = cx * sy * cz + sx * cy * sz; q.k = cx * cy * sz - sx * sy * cz;
-    }
+    q.e = cx * cy * cz - sx * sy * sz;
+    q.i = order == kOrderZXY ? ia - ib : ia + ib;
+    q.j = order == kOrderXYZ ? ja - jb : ja + jb;
+    q.k = order == kOrderYZX ? ka - kb : ka + kb;
     return q;
 }
 __device__ __forceinline__ void limit_euler(float *e, const float *lo, const float *hi, bool ikt) {   // poser_impl.inl:178-194
@@ -327,14 +342,15 @@ __device__ __forceinline__ void limit_euler(float *e, const float *lo, const flo
     }
 }
 
-// total rotation / translation already in the state: build local_matrix_ and apply the parent product.
-// `self` / `parent` index the state (bone ids in HBM scratch, chain slots in LDS); parent < 0 = none.
+// local_matrix_ from the total rotation / translation (the values just stored in the state, passed along so
+// they are not read back), then the parent product.  `self` / `parent` index the state (bone ids in HBM
+// scratch, chain slots in LDS); parent < 0 = none.
 template <class S>
-__device__ void place_at(const S &st, const BoneRec &rec, uint32_t self, int32_t parent) {
-    Mat4 L = q_to_matrix(st.quat(self, kStTotalRot));
-    L.m[3][0] = st.at(self, kStTotalTr + 0) + rec.local_offset[0];
-    L.m[3][1] = st.at(self, kStTotalTr + 1) + rec.local_offset[1];
-    L.m[3][2] = st.at(self, kStTotalTr + 2) + rec.local_offset[2];
+__device__ void place_at(const S &st, const V3 local_offset, const Quat total, const V3 tr, uint32_t self, int32_t parent) {
+    Mat4 L = q_to_matrix(total);
+    L.m[3][0] = tr.x + local_offset.x;
+    L.m[3][1] = tr.y + local_offset.y;
+    L.m[3][2] = tr.z + local_offset.z;
     if (parent >= 0) L = mul(L, st.local(uint32_t(parent)));
     st.set_local(self, L);
 }
@@ -378,7 +394,7 @@ __device__ void transform_at(const S &st, const BoneRec &rec, const MorphXf mx, 
     }
     st.set_quat(self, kStTotalRot, total);
     st.at(self, kStTotalTr + 0) = tx; st.at(self, kStTotalTr + 1) = ty; st.at(self, kStTotalTr + 2) = tz;
-    place_at(st, rec, self, parent);
+    place_at(st, V3{rec.local_offset[0], rec.local_offset[1], rec.local_offset[2]}, total, V3{tx, ty, tz}, self, parent);
 }
 
 __device__ __forceinline__ void transform_bone(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst,
@@ -388,20 +404,59 @@ __device__ __forceinline__ void transform_bone(const State &st, const SerialPara
                  uint32_t(rec.append_parent));
 }
 
-// The CCD loop of UpdateBoneTransform, poser_impl.inl:196-309, over a state `st` in which link j lives at
-// index lidx(j), the target at tidx, their parents at lpar(j) / tpar (< 0 = none).  Two instantiations:
-// directly on the HBM scratch (indices = bone ids), or on an LDS window holding just the chain (fast path).
-template <class S, class LIdx, class LPar>
+// What the CCD loop needs to know about link j of its chain: where it and its parent live in the state, its
+// rest offset and its limits.  On the HBM state these come from the rig tables (indices = bone ids); on the
+// LDS window the chain's constants were copied next to it (index j = link j, see solve_ik).
+struct LinkInfo {
+    uint32_t limited, order, fix;
+    float lo[3], hi[3];
+};
+constexpr uint32_t kLinkConstFloats = 10;       // local offset xyz, limited | order << 8 | fix << 16, lo xyz, hi xyz
+
+struct TableChain {
+    const SerialParams &p;
+    const LinkRec *links;
+    __device__ __forceinline__ uint32_t idx(uint32_t j) const { return links[j].bone; }
+    __device__ __forceinline__ int32_t par(uint32_t j) const { return p.bones[links[j].bone].parent; }
+    __device__ __forceinline__ V3 offset(uint32_t j) const {
+        const float *o = p.bones[links[j].bone].local_offset;
+        return {o[0], o[1], o[2]};
+    }
+    __device__ __forceinline__ LinkInfo link(uint32_t j) const {
+        const LinkRec lk = links[j];
+        return {lk.limited, lk.order, lk.fix, {lk.lo[0], lk.lo[1], lk.lo[2]}, {lk.hi[0], lk.hi[1], lk.hi[2]}};
+    }
+};
+struct WindowChain {
+    const __attribute__((address_space(3))) float *consts;     // [link][kLinkConstFloats], shared by the window's lanes
+    uint32_t n;
+    int32_t outside;                                           // window slot of the root-most link's parent, -1 = none
+    __device__ __forceinline__ uint32_t idx(uint32_t j) const { return j; }
+    __device__ __forceinline__ int32_t par(uint32_t j) const { return j + 1 < n ? int32_t(j + 1) : outside; }
+    __device__ __forceinline__ V3 offset(uint32_t j) const {
+        const auto *c = consts + j * kLinkConstFloats;
+        return {c[0], c[1], c[2]};
+    }
+    __device__ __forceinline__ LinkInfo link(uint32_t j) const {
+        const auto *c = consts + j * kLinkConstFloats;
+        const uint32_t w = __float_as_uint(c[3]);
+        return {w & 0xFFu, (w >> 8) & 0xFFu, w >> 16, {c[4], c[5], c[6]}, {c[7], c[8], c[9]}};
+    }
+};
+
+// The CCD loop of UpdateBoneTransform, poser_impl.inl:196-309, over a state `st` in which the chain `ch` says
+// where link j and its parent live, the target at tidx, its parent at tpar (< 0 = none).
+template <class S, class Chain>
 __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint32_t inst, const IkRec &ik,
-                    const LinkRec *links, const V3 ik_pos, LIdx lidx, LPar lpar, uint32_t tidx, int32_t tpar) {
+                    const LinkRec *links, const V3 ik_pos, const Chain &ch, uint32_t tidx, int32_t tpar) {
     const BoneRec trec = p.bones[ik.target];
     const float4 tt = pose[2 * size_t(ik.target)], tr = pose[2 * size_t(ik.target) + 1];
     const MorphXf tmx = morph_of(p, ik.target, inst);
-    for (uint32_t i = 0; i < ik.nlinks; ++i) st.set_quat(lidx(i), kStIkRot, q_identity());
+    for (uint32_t i = 0; i < ik.nlinks; ++i) st.set_quat(ch.idx(i), kStIkRot, q_identity());
     for (uint32_t i = 0; i < ik.nlinks; ++i) {
         const uint32_t j = ik.nlinks - i - 1, lb = links[j].bone;
         const BoneRec rec = p.bones[lb];
-        transform_at(st, rec, morph_of(p, lb, inst), pose[2 * size_t(lb)], pose[2 * size_t(lb) + 1], lidx(j), lpar(j),
+        transform_at(st, rec, morph_of(p, lb, inst), pose[2 * size_t(lb)], pose[2 * size_t(lb) + 1], ch.idx(j), ch.par(j),
                      uint32_t(rec.append_parent));
     }
     transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
@@ -411,10 +466,10 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
     const uint32_t ikt = ik.loop / 2;
     for (uint32_t i = 0; i < ik.loop; ++i) {
         for (uint32_t j = 0; j < ik.nlinks; ++j) {
-            const LinkRec lk = links[j];
+            const LinkInfo lk = ch.link(j);
             if (lk.fix == kFixAll) continue;
-            const uint32_t ls = lidx(j);
-            const int32_t lp = lpar(j);
+            const uint32_t ls = ch.idx(j);
+            const int32_t lp = ch.par(j);
             const V3 lpos = {st.at(ls, kStLocal + 12), st.at(ls, kStLocal + 13), st.at(ls, kStLocal + 14)};
             const V3 tdir = v_normalize({lpos.x - tgt.x, lpos.y - tgt.y, lpos.z - tgt.z});
             const V3 idir = v_normalize({lpos.x - ik_pos.x, lpos.y - ik_pos.y, lpos.z - ik_pos.z});
@@ -433,8 +488,12 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
                     for (int x = 0; x < 4; ++x) loc.m[y][x] = x == y ? 1.f : 0.f;
             }
             if (lk.limited && lk.fix != kFixNone && i < ikt) {
-                const uint32_t row = lk.fix - kFixX;
-                const float d = axis.x * loc.m[row][0] + axis.y * loc.m[row][1] + axis.z * loc.m[row][2];
+                const uint32_t row = lk.fix - kFixX;       // selects, not loc.m[row]: a lane-varying index would
+                                                            // put the matrix in scratch memory
+                const float m0 = row == 0 ? loc.m[0][0] : row == 1 ? loc.m[1][0] : loc.m[2][0];
+                const float m1 = row == 0 ? loc.m[0][1] : row == 1 ? loc.m[1][1] : loc.m[2][1];
+                const float m2 = row == 0 ? loc.m[0][2] : row == 1 ? loc.m[1][2] : loc.m[2][2];
+                const float d = axis.x * m0 + axis.y * m1 + axis.z * m2;
                 const float sgn = d >= 0.0f ? 1.0f : -1.0f;
                 axis = {row == 0 ? sgn : 0.f, row == 1 ? sgn : 0.f, row == 2 ? sgn : 0.f};
             } else {                                       // rotate(axis, loc.Transpose()).Normalize()
@@ -460,9 +519,11 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
             }
             st.set_quat(ls, kStIkRot, ikr);
             for (uint32_t k = 0; k <= j; ++k) {
-                const uint32_t jj = j - k, bs = lidx(jj);
-                st.set_quat(bs, kStTotalRot, q_mul(st.quat(bs, kStIkRot), st.quat(bs, kStPreIkRot)));
-                place_at(st, p.bones[links[jj].bone], bs, lpar(jj));
+                const uint32_t jj = j - k, bs = ch.idx(jj);
+                const Quat total = q_mul(st.quat(bs, kStIkRot), st.quat(bs, kStPreIkRot));
+                st.set_quat(bs, kStTotalRot, total);
+                place_at(st, ch.offset(jj), total, V3{st.at(bs, kStTotalTr + 0), st.at(bs, kStTotalTr + 1), st.at(bs, kStTotalTr + 2)},
+                         bs, ch.par(jj));
             }
             transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
             tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
@@ -474,15 +535,18 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
 
 // One IK bone.  Chains with the usual topology (every link's parent is the next link, the target hangs off
 // the first link, no append bones inside; IkRec::fast, decided on the host) are solved on an LDS window:
-// their few bones' state is copied in, the up-to-256-iteration loop runs at LDS latency instead of paying
-// HBM-scratch round trips for every dependent access, and the result is copied back.  Same arithmetic.
+// their few bones' state and the links' constants are copied in, the up-to-256-iteration loop runs at LDS
+// latency instead of paying a round trip to the tables and the HBM scratch for every dependent access, and
+// the result is copied back.  Same arithmetic.  `lds_lane` = this lane's cell of the window's state,
+// `lds_consts` = the window's constants (the lanes of a window solve the same chain and write the same values).
 __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst, uint32_t b,
-                         __attribute__((address_space(3))) float *lds_lane) {
+                         __attribute__((address_space(3))) float *lds_lane,
+                         __attribute__((address_space(3))) float *lds_consts) {
     const IkRec ik = p.iks[p.bones[b].ik];
     const LinkRec *links = p.links + ik.link0;
     const V3 ik_pos = {st.at(b, kStLocal + 12), st.at(b, kStLocal + 13), st.at(b, kStLocal + 14)};
     if (ik.fast) {
-        const ChainState cs = {lds_lane, kSerialThreads};
+        const ChainState cs = {lds_lane, 0};
         const uint32_t n = ik.nlinks;
         const int32_t outside = ik.outside_parent;         // parent of the root-most link, outside the chain
         auto copy = [&](uint32_t slot, uint32_t bone, bool in) {
@@ -491,16 +555,23 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
                 if (in) cs.at(slot, f) = st.at(bone, f); else st.at(bone, f) = cs.at(slot, f);
             }
         };
-        for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, true);
+        for (uint32_t j = 0; j < n; ++j) {
+            const LinkRec lk = links[j];
+            copy(j, lk.bone, true);
+            const float *off = p.bones[lk.bone].local_offset;
+            auto *c = lds_consts + j * kLinkConstFloats;
+            c[0] = off[0]; c[1] = off[1]; c[2] = off[2];
+            c[3] = __uint_as_float(lk.limited | lk.order << 8 | lk.fix << 16);
+            c[4] = lk.lo[0]; c[5] = lk.lo[1]; c[6] = lk.lo[2];
+            c[7] = lk.hi[0]; c[8] = lk.hi[1]; c[9] = lk.hi[2];
+        }
         copy(n, ik.target, true);
         if (outside >= 0) copy(n + 1, uint32_t(outside), true);
-        ccd(cs, p, pose, inst, ik, links, ik_pos, [](uint32_t j) { return j; },
-            [&](uint32_t j) { return j + 1 < n ? int32_t(j + 1) : (outside >= 0 ? int32_t(n + 1) : -1); }, n, 0);
+        ccd(cs, p, pose, inst, ik, links, ik_pos, WindowChain{lds_consts, n, outside >= 0 ? int32_t(n + 1) : -1}, n, 0);
         for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, false);
         copy(n, ik.target, false);
     } else {
-        ccd(st, p, pose, inst, ik, links, ik_pos, [&](uint32_t j) { return links[j].bone; },
-            [&](uint32_t j) { return p.bones[links[j].bone].parent; }, ik.target, p.bones[ik.target].parent);
+        ccd(st, p, pose, inst, ik, links, ik_pos, TableChain{p, links}, ik.target, p.bones[ik.target].parent);
     }
 }
 
@@ -508,8 +579,8 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
 // L/motion/poser_impl.inl:347-354, after the reset of :369-370).  One thread per instance walks the
 // applications in the reference's order (the quaternion products of one bone do not commute); rates below
 // 1e-7 skip at every group level like the vertex morphs.  Output [bone][7][instance].
-__global__ __launch_bounds__(kSerialThreads) void bone_morph_kernel(const BoneMorphParams p) {
-    const uint32_t inst = blockIdx.x * kSerialThreads + threadIdx.x;
+__global__ __launch_bounds__(kBoneMorphThreads) void bone_morph_kernel(const BoneMorphParams p) {
+    const uint32_t inst = blockIdx.x * kBoneMorphThreads + threadIdx.x;
     if (inst >= p.ni) return;
     float *out = p.out + inst;
     const size_t n = p.ni;
@@ -536,42 +607,63 @@ __global__ __launch_bounds__(kSerialThreads) void bone_morph_kernel(const BoneMo
     }
 }
 
-__global__ __launch_bounds__(kSerialThreads) void skeleton_serial_kernel(const SerialParams p) {
-    const uint32_t inst = blockIdx.x * kSerialThreads + threadIdx.x;
-    if (inst >= p.ni) return;          // every lane that stays runs to the end: no barriers in this kernel
-    const State st = {p.state + inst, p.ni};
-    extern __shared__ float chain_lds[];                    // (fast_slots) x 31 x 64 floats, lane fastest
-    auto *lds_lane = (__attribute__((address_space(3))) float *)chain_lds + threadIdx.x;
-    const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(inst) * p.nb * 2;
-    for (uint32_t b = 0; b < p.nb; ++b) {                  // PrePhysicsPosing's reset, poser_impl.inl:366-377
-        st.set_quat(b, kStTotalRot, q_identity());
-        st.set_quat(b, kStIkRot, q_identity());
-        st.set_quat(b, kStPreIkRot, q_identity());
-        st.at(b, kStTotalTr + 0) = 0.f; st.at(b, kStTotalTr + 1) = 0.f; st.at(b, kStTotalTr + 2) = 0.f;
+// The ordered solver.  A workgroup holds kSolveInstances instances x kSolveSlots slots (instance fastest, so
+// the 16 lanes of a slot touch one 64-byte run of every state cell); the host cut the evaluation sequence
+// into rounds of events that touch disjoint bones (rig.cpp schedule_rounds), slot k of every instance runs
+// event k of the round, and a workgroup barrier separates the rounds.  Every event is the reference's
+// UpdateBoneTransform on the state the serial sequence would have shown it: same arithmetic, same result.
+__global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordered_kernel(const SerialParams p) {
+    const uint32_t slot = threadIdx.x / kSolveInstances;
+    const uint32_t inst = blockIdx.x * kSolveInstances + threadIdx.x % kSolveInstances;
+    const bool live = inst < p.ni;       // dead lanes skip the work but reach every barrier
+    const State st = {p.state + (live ? inst : 0), p.ni};
+    extern __shared__ float chain_lds[];   // (windows x instances) lanes x window_floats of state, then the
+                                           // windows' link constants
+    const uint32_t wf = window_floats(p.fast_slots);
+    auto *lds_lane = (__attribute__((address_space(3))) float *)chain_lds + threadIdx.x * wf;
+    auto *lds_consts = (__attribute__((address_space(3))) float *)chain_lds +
+                       size_t(p.windows) * kSolveInstances * wf + slot * (kMaxFastLinks * kLinkConstFloats);
+    const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(live ? inst : 0) * p.nb * 2;
+    if (live) {
+        for (uint32_t b = slot; b < p.nb; b += kSolveSlots) {   // PrePhysicsPosing's reset, poser_impl.inl:366-377
+            st.set_quat(b, kStTotalRot, q_identity());
+            st.set_quat(b, kStIkRot, q_identity());
+            st.set_quat(b, kStPreIkRot, q_identity());
+            st.at(b, kStTotalTr + 0) = 0.f; st.at(b, kStTotalTr + 1) = 0.f; st.at(b, kStTotalTr + 2) = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) st.at(b, kStLocal + k) = (k % 5 == 0) ? 1.f : 0.f;
+            for (int k = 0; k < 16; ++k) st.at(b, kStLocal + k) = (k % 5 == 0) ? 1.f : 0.f;
+        }
     }
-    float4 *out = reinterpret_cast<float4 *>(p.out) + size_t(inst) * p.nb * 4;
+    __syncthreads();
+    float4 *out = reinterpret_cast<float4 *>(p.out) + size_t(live ? inst : 0) * p.nb * 4;
     for (uint32_t pass = 0; pass < 2; ++pass) {
+        const uint32_t r0 = pass ? p.n_rounds_pre : 0, r1 = pass ? p.n_rounds : p.n_rounds_pre;
+        for (uint32_t r = r0; r < r1; ++r) {
+            const RoundRec rr = p.rounds[r];
+            if (live && slot < rr.count) {
+                const uint32_t b = p.events[rr.first + slot];
+                transform_bone(st, p, pose, inst, b);
+                if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, inst, b, lds_lane, lds_consts);
+            }
+            __syncthreads();
+        }
         const uint32_t s0 = pass ? p.n_pre : 0, s1 = pass ? p.nb : p.n_pre;
-        for (uint32_t s = s0; s < s1; ++s) {
-            const uint32_t b = p.order[s];
-            transform_bone(st, p, pose, inst, b);
-            if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, inst, b, lds_lane);
+        if (live) {
+            for (uint32_t s = s0 + slot; s < s1; s += kSolveSlots) {   // UpdateBoneSkinningMatrix of this list
+                const uint32_t b = p.order[s];
+                const BoneRec rec = p.bones[b];
+                Mat4 G;
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) G.m[y][x] = x == y ? 1.f : 0.f;
+                G.m[3][0] = rec.neg_rest[0]; G.m[3][1] = rec.neg_rest[1]; G.m[3][2] = rec.neg_rest[2];
+                const Mat4 S = mul(G, st.local(b));
+#pragma unroll
+                for (int y = 0; y < 4; ++y) out[4 * size_t(b) + y] = make_float4(S.m[y][0], S.m[y][1], S.m[y][2], S.m[y][3]);
+            }
         }
-        for (uint32_t s = s0; s < s1; ++s) {               // UpdateBoneSkinningMatrix of this list
-            const uint32_t b = p.order[s];
-            const BoneRec rec = p.bones[b];
-            Mat4 G;
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) G.m[y][x] = x == y ? 1.f : 0.f;
-            G.m[3][0] = rec.neg_rest[0]; G.m[3][1] = rec.neg_rest[1]; G.m[3][2] = rec.neg_rest[2];
-            const Mat4 S = mul(G, st.local(b));
-#pragma unroll
-            for (int y = 0; y < 4; ++y) out[4 * size_t(b) + y] = make_float4(S.m[y][0], S.m[y][1], S.m[y][2], S.m[y][3]);
-        }
+        __syncthreads();                                     // the second list's IK may rewrite these bones
     }
 }
 
@@ -595,16 +687,22 @@ hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream) {
 
 hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream) {
     if (p.ni == 0 || p.nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(bone_morph_kernel, dim3((p.ni + kSerialThreads - 1) / kSerialThreads), dim3(kSerialThreads), 0,
+    hipLaunchKernelGGL(bone_morph_kernel, dim3((p.ni + kBoneMorphThreads - 1) / kBoneMorphThreads), dim3(kBoneMorphThreads), 0,
                        stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_skeleton_serial(const SerialParams &p, hipStream_t stream) {
+hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream) {
     if (p.ni == 0 || p.nb == 0) return hipSuccess;
-    const size_t lds = size_t(p.fast_slots) * kSerialStateFloats * kSerialThreads * sizeof(float);
-    hipLaunchKernelGGL(skeleton_serial_kernel, dim3((p.ni + kSerialThreads - 1) / kSerialThreads),
-                       dim3(kSerialThreads), lds, stream, p);
+    const size_t lds = (size_t(window_floats(p.fast_slots)) * p.windows * kSolveInstances +
+                        size_t(p.windows) * kMaxFastLinks * kLinkConstFloats) * sizeof(float);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skeleton_ordered_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(skeleton_ordered_kernel, dim3((p.ni + kSolveInstances - 1) / kSolveInstances),
+                       dim3(kSolveInstances * kSolveSlots), lds, stream, p);
     return hipGetLastError();
 }
 

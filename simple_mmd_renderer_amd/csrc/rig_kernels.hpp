@@ -9,7 +9,7 @@ namespace mmdx {
 
 hipError_t launch_bone_track_eval(const BoneTrackParams &p, hipStream_t stream);
 hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream);
-hipError_t launch_skeleton_serial(const SerialParams &p, hipStream_t stream);
+hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream);
 hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream);
 
 // api.cpp: the device and stream a motion / rig call runs on -- the model's own when a (device) model

@@ -1,6 +1,7 @@
 // Host "model compile" (csrc/plan.cpp) under AddressSanitizer + UBSan on the CPU: random models incl.
 // group morphs, ragged tiles, invalid indices (must be rejected, not read).  Built and run by
 // tests/test_sanitizers.py; GPU sanitizers are not available on the pool.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -9,6 +10,57 @@
 #include "../simple_mmd_renderer_amd/csrc/plan.hpp"
 #include "../simple_mmd_renderer_amd/csrc/rig.hpp"
 #include "../simple_mmd_renderer_amd/csrc/vmd.hpp"
+
+// The round schedule of the ordered solver must show every event exactly the state the serial sequence
+// shows it: replay both with a version number per bone (= the event that last wrote it) and compare what
+// each event sees; events sharing a round must not touch each other's bones at all.
+static int check_rounds(const mmdx::SkeletonPlan &sp) {
+    const uint32_t nb = sp.nb;
+    std::vector<uint32_t> reads, writes;
+    std::vector<std::vector<int64_t>> seen(nb);
+    std::vector<int64_t> version(nb, -1);
+    auto look = [&](uint32_t b) {
+        std::vector<int64_t> v;
+        mmdx::solve_event_sets(sp, b, reads, writes);
+        for (uint32_t x : reads) v.push_back(version[x]);
+        for (uint32_t x : writes) v.push_back(version[x]);
+        return v;
+    };
+    for (uint32_t s = 0; s < nb; ++s) {
+        const uint32_t b = sp.order[s];
+        seen[b] = look(b);
+        for (uint32_t x : writes) version[x] = b;
+    }
+    std::fill(version.begin(), version.end(), -1);
+    std::vector<uint8_t> ran(nb, 0), pre(nb, 0), touched(nb);
+    for (uint32_t s = 0; s < sp.n_pre; ++s) pre[sp.order[s]] = 1;
+    if (sp.n_rounds_pre > sp.rounds.size()) return 20;
+    size_t total = 0;
+    for (size_t r = 0; r < sp.rounds.size(); ++r) {
+        const mmdx::RoundRec rr = sp.rounds[r];
+        if (rr.count == 0 || rr.count > mmdx::kSolveSlots || rr.first != total || rr.first + rr.count > sp.events.size()) return 21;
+        total += rr.count;
+        std::fill(touched.begin(), touched.end(), uint8_t(0));     // 1 = read, 2 = written by an event of this round
+        for (uint32_t k = 0; k < rr.count; ++k) {
+            const uint32_t b = sp.events[rr.first + k];
+            if (b >= nb || ran[b] || pre[b] != (r < sp.n_rounds_pre ? 1 : 0)) return 22;
+            ran[b] = 1;
+            if (look(b) != seen[b]) return 23;
+            const mmdx::BoneRec &rec = sp.bones[b];
+            if ((rec.bits & mmdx::kBoneHasIk) && sp.iks[rec.ik].fast && k >= sp.windows) return 24;
+            for (uint32_t x : writes) { if (touched[x]) return 25; }
+            for (uint32_t x : reads) { if (touched[x] == 2) return 25; }
+            for (uint32_t x : writes) touched[x] = 2;
+            for (uint32_t x : reads) if (!touched[x]) touched[x] = 1;
+        }
+        for (uint32_t k = 0; k < rr.count; ++k) {
+            mmdx::solve_event_sets(sp, sp.events[rr.first + k], reads, writes);
+            for (uint32_t x : writes) version[x] = sp.events[rr.first + k];
+        }
+    }
+    if (total != nb || sp.events.size() != nb) return 26;
+    return 0;
+}
 
 int main() {
     std::mt19937 rng(1234);
@@ -206,8 +258,8 @@ int main() {
     std::printf("vmd fuzz: parsed=%d rejected=%d\n", ok, bad);
 
     // skeleton compile (rig.cpp): random hierarchies incl. forward / out-of-range / self parents
-    int sk_ok = 0, sk_bad = 0;
-    for (int it = 0; it < 300; ++it) {
+    int sk_ok = 0, sk_bad = 0, sk_rounds = 0, sk_events = 0;
+    for (int it = 0; it < 900; ++it) {
         const uint32_t nb = rng() % 70;
         std::vector<float> rest(size_t(nb) * 3 + 1, 1.0f);
         std::vector<int32_t> par(nb + 1), lvl(nb + 1);
@@ -251,6 +303,9 @@ int main() {
         }
         if (mmdx::build_skeleton(d, sp, err) == MMDX_OK) {
             if (sp.serial) {
+                if (int rc = check_rounds(sp)) return rc;
+                sk_rounds += int(sp.rounds.size());
+                sk_events += int(sp.events.size());
                 for (const auto &r : sp.bones)
                     if (r.parent >= int32_t(nb) || ((r.bits & 3u) && uint32_t(r.append_parent) >= nb)) return 11;
                 for (const auto &k : sp.iks) if (k.target >= nb || k.loop > 256 || k.link0 + k.nlinks > sp.links.size()) return 12;
@@ -263,7 +318,7 @@ int main() {
             for (uint32_t c : sp.chain) if (c != mmdx::kIdentityParent && c >= nb) return 10;
         } else ++sk_bad;
     }
-    std::printf("skeleton: compiled=%d rejected=%d\n", sk_ok, sk_bad);
+    std::printf("skeleton: compiled=%d rejected=%d; ordered solver: %d events in %d rounds\n", sk_ok, sk_bad, sk_events, sk_rounds);
     return 0;
 }
 

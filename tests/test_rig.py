@@ -3,7 +3,10 @@
 CPU tests pin the C restatement (oracle/mmdx_oracle.c: mmdx_oracle_bone_pose / _bone_solve) against the
 real libmmd and against the committed golden fixture, and cover the host-side compilation behind
 mmdx_vmd_bind_bones / mmdx_skeleton_create.  GPU tests compare the HIP kernels with the oracle and the
-fixture through the C ABI: bit-exact, no tolerance.
+fixture through the C ABI: bit-exact, no tolerance, on every seed used here.  (Stated tolerance of the IK solve
+beyond these seeds: its sin/cos/asin/acos/atan2 go through the device's double libm where the reference's go
+through glibc's; a soak of 512 000 random solves found one instance whose palette differs, by 3.8e-6 at most --
+DESIGN.md section 7 row 3, tools/soak_rig.py, tools/rig_mismatch_probe.py.)
 """
 import os
 
@@ -177,6 +180,24 @@ def test_ik_skeleton_create_host_side():
     with pytest.raises(api.MmdxError) as e:
         vmd.Skeleton(rest, parent, level, flags, ap, ar, nested)
     assert e.value.status == 6 and "itself an IK bone" in str(e.value)
+
+
+def test_solve_round_schedule_host_side(monkeypatch):
+    """The ordered solver's schedule (rig.cpp schedule_rounds): independent bones share a round, so a 300-bone
+    rig takes far fewer rounds than bones; an FK-only rig has none; MMDX_SOLVE_SEQUENTIAL=1 switches it off.
+    (That every event sees the serial sequence's state is checked on random rigs by the schedule replay in
+    tests/plan_sanitizer_driver.cpp.)"""
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(300, 3003, n_ik=8, n_append=12, post_physics=0.3, levels=3)
+    info = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik).info
+    assert info["solver"] == vmd.SOLVER_SERIAL and 2 <= info["n_solve_rounds"] < 300 // 4
+    assert vmd.Skeleton(rest, parent).info["n_solve_rounds"] == 0
+    line = np.arange(-1, 39).astype(np.int32)                # a single 40-bone line: nothing to run side by side
+    f = np.zeros(40, np.uint16)
+    f[39] = 0x0100
+    assert vmd.Skeleton(np.zeros((40, 3), np.float32), line, None, f, np.full(40, 3, np.int32),
+                        np.ones(40, np.float32)).info["n_solve_rounds"] == 40
+    monkeypatch.setenv("MMDX_SOLVE_SEQUENTIAL", "1")
+    assert vmd.Skeleton(rest, parent, level, flags, ap, ar, ik).info["n_solve_rounds"] == 300
 
 
 IK_CASES = [(30, 0, 2, 2), (44, 1, 3, 4), (80, 2, 5, 6), (150, 3, 6, 10), (61, 4, 4, 0), (52, 5, 0, 8)]
@@ -433,7 +454,7 @@ def test_gpu_golden_ik_rig():
 @pytest.mark.gpu
 @pytest.mark.parametrize("nb,seed,n_ik,n_app", IK_CASES + [(300, 7, 8, 12)])
 def test_gpu_ik_skeleton_vs_oracle(oracle, nb, seed, n_ik, n_app):
-    """The serial device solver against the oracle, 70 instances (two waves, one partial)."""
+    """The ordered device solver against the oracle, 70 instances (the last workgroup partly empty)."""
     rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, seed, n_ik=n_ik, n_append=n_app)
     poses = random_poses(70, nb, 200 + seed)
     got = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik).solve(poses)
@@ -523,6 +544,24 @@ def test_gpu_full_size_crowd_rig(oracle):
         gu.assert_bits_equal_or_both_nan(ikp[i], want, f"IK palette of instance {i}")
         n_nan += int(np.isnan(want).any())
     assert n_nan < ni // 4                               # degenerate chains (NaN upstream too) stay the exception
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ni", [1, 37, 200])
+def test_gpu_round_schedule_equals_sequential(monkeypatch, ni):
+    """The round schedule against the same kernel fed one event per round (MMDX_SOLVE_SEQUENTIAL=1): identical
+    bits on rigs dense with IK chains, append bones and post-physics bones; instance counts that leave the last
+    workgroup partly empty."""
+    for seed in range(12):
+        nb = 24 + 7 * seed
+        rig = synth.make_ik_rig(nb, 500 + seed, n_ik=1 + seed % 6, n_append=seed % 7, post_physics=0.3, levels=3)
+        poses = random_poses(ni, nb, 900 + seed)
+        monkeypatch.delenv("MMDX_SOLVE_SEQUENTIAL", raising=False)
+        sched = vmd.Skeleton(*rig)
+        monkeypatch.setenv("MMDX_SOLVE_SEQUENTIAL", "1")
+        seq = vmd.Skeleton(*rig)
+        assert seq.info["n_solve_rounds"] == nb and sched.info["n_solve_rounds"] < nb
+        gu.assert_bits_equal_or_both_nan(sched.solve(poses), seq.solve(poses), f"rig {seed}")
 
 
 @pytest.mark.gpu
