@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -171,6 +172,23 @@ mmdx_status mmdx::resolve_stream(mmdx_model_t model, int *device, hipStream_t *s
     return MMDX_OK;
 }
 mmdx_status mmdx::hip_status(hipError_t e, const char *what) { return hip_fail(e, what); }
+
+// The wait at the end of a call that hands results back to the host.  A per-frame call is tens of
+// microseconds of device work; hipStreamSynchronize may put the thread to sleep and then pays a wake-up that is
+// several times that on some hosts (tools/host_io_probe.py), so poll the stream first and only fall back to the
+// blocking wait when the work is long.  MMDX_SPIN_WAIT_US: polling budget in microseconds (default 2000, 0 = off).
+hipError_t mmdx::wait_stream(hipStream_t stream) {
+    static const int spin_us = env_int("MMDX_SPIN_WAIT_US", 2000);
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e != hipErrorNotReady) return e;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+        }
+    }
+    return hipStreamSynchronize(stream);
+}
 
 extern "C" {
 
@@ -474,11 +492,11 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     if (!out_dev) {
         HIP_TRY(hipMemcpyAsync(a->out_a, dp.out_a, bytes_a, hipMemcpyDeviceToHost, st));
         if (bytes_b) HIP_TRY(hipMemcpyAsync(a->out_b, dp.out_b, bytes_b, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(wait_stream(st));
     } else if (!(a->flags & MMDX_PALETTE_ON_DEVICE) ||
                (morph != kMorphNone && !(a->flags & MMDX_WEIGHTS_ON_DEVICE))) {
         // borrowed host inputs must be consumed before we return
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(wait_stream(st));
     }
     return MMDX_OK;
 }
@@ -513,7 +531,7 @@ mmdx_status mmdx_sync(mmdx_model_t m) {
     if (!m) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL");
     if (m->device < 0) return fail(MMDX_ERR_NO_DEVICE, "host-only model");
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(wait_stream(m->stream));
     return MMDX_OK;
 }
 
@@ -618,9 +636,9 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
     HIP_TRY(launch_morph_track_eval(t, st));
     if (!(flags & MMDX_OUT_ON_DEVICE)) {
         if (out_bytes) HIP_TRY(hipMemcpyAsync(out_weights, t.out, out_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(wait_stream(st));
     } else if (!(flags & MMDX_FRAMES_ON_DEVICE)) {
-        HIP_TRY(hipStreamSynchronize(st));   // borrowed host frames must be consumed before returning
+        HIP_TRY(wait_stream(st));   // borrowed host frames must be consumed before returning
     }
     return MMDX_OK;
 }

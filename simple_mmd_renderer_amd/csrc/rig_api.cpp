@@ -142,9 +142,9 @@ mmdx_status mmdx_bone_motion_eval(mmdx_bone_motion_t m, mmdx_model_t model, uint
     HIP_TRY(launch_bone_track_eval(p, st));
     if (!(flags & MMDX_OUT_ON_DEVICE)) {
         if (out_bytes) HIP_TRY(hipMemcpyAsync(out_poses, p.out, out_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(wait_stream(st));
     } else if (!(flags & MMDX_FRAMES_ON_DEVICE)) {
-        HIP_TRY(hipStreamSynchronize(st));   // borrowed host frames must be consumed before returning
+        HIP_TRY(wait_stream(st));   // borrowed host frames must be consumed before returning
     }
     return MMDX_OK;
 }
@@ -291,9 +291,9 @@ mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, u
     }
     if (!(flags & MMDX_OUT_ON_DEVICE)) {
         if (out_bytes) HIP_TRY(hipMemcpyAsync(out_palettes, p.out, out_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(wait_stream(st));
     } else if (!(flags & MMDX_POSES_ON_DEVICE) || borrowed_rates) {
-        HIP_TRY(hipStreamSynchronize(st));   // borrowed host poses / rates must be consumed before returning
+        HIP_TRY(wait_stream(st));   // borrowed host poses / rates must be consumed before returning
     }
     return MMDX_OK;
 }

@@ -17,5 +17,7 @@ hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream);
 // default stream.  Fails with MMDX_ERR_NO_DEVICE when there is no GPU (no CPU fallback).
 mmdx_status resolve_stream(mmdx_model_t model, int *device, hipStream_t *stream);
 mmdx_status hip_status(hipError_t e, const char *what);
+// api.cpp: host-visible completion of the work queued on `stream` (see there).
+hipError_t wait_stream(hipStream_t stream);
 
 }  // namespace mmdx
