@@ -204,8 +204,11 @@ MMDX_API mmdx_status mmdx_profile_collect(mmdx_model_t model, uint32_t *n_calls,
  * the HIP runtime themselves. */
 MMDX_API mmdx_status mmdx_device_malloc(void **ptr, size_t bytes);
 MMDX_API mmdx_status mmdx_device_free(void *ptr);
-/* Page-locked host memory: palettes / rates / vertex buffers handed to mmdx_deform*() from here move
- * over PCIe by DMA without the runtime's staging copy (the single-model drop-in path). */
+/* Page-locked host memory: palettes / rates handed to mmdx_deform*() from here move over PCIe by DMA
+ * without the runtime's staging copy, and OUTPUT buffers from here (or any hipHostMalloc / hipHostRegister
+ * memory) are written by the kernel directly -- no device-side staging buffer, no device-to-host copy
+ * command: the single-model drop-in path (the viewer's vertex buffer, main.cpp:735-863).  Pageable
+ * memory works everywhere too, through staging copies. */
 MMDX_API mmdx_status mmdx_host_malloc(void **ptr, size_t bytes);
 MMDX_API mmdx_status mmdx_host_free(void *ptr);
 MMDX_API mmdx_status mmdx_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);

@@ -95,6 +95,26 @@ namespace {
 
 constexpr size_t kMaxProfiledCalls = 1 << 16;
 
+// The device-side address of a host pointer that lies in page-locked, device-mapped memory; nullptr for
+// pageable memory (and for device memory: callers pass that with the *_ON_DEVICE flags).  MMDX_HOST_DIRECT=0
+// turns the direct path off (A/B against the staging copy).
+void *mapped_host_pointer(const void *host) {
+    static const bool enabled = [] { const char *e = std::getenv("MMDX_HOST_DIRECT"); return !(e && e[0] == '0'); }();
+    if (!enabled || !host) return nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess) {
+        (void)hipGetLastError();                    // pageable memory: "invalid value", not an error of ours
+        return nullptr;
+    }
+    if (attr.type != hipMemoryTypeHost) return nullptr;
+    void *dev = nullptr;                            // interior pointers are fine: the offset carries over
+    if (hipHostGetDevicePointer(&dev, const_cast<void *>(host), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return dev;
+}
+
 int env_int(const char *name, int dflt) {
     const char *s = std::getenv(name);
     return s && *s ? std::atoi(s) : dflt;
@@ -433,12 +453,23 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // ---- outputs ---------------------------------------------------------------------------------
     const size_t bytes_a = out_bytes_a(layout, nvi), bytes_b = out_bytes_b(layout, nvi);
     const bool out_dev = (a->flags & MMDX_OUT_ON_DEVICE) != 0;
+    // Host outputs in page-locked, device-mapped memory (mmdx_host_malloc / hipHostMalloc / hipHostRegister): the
+    // kernel stores straight into them over PCIe -- 16-byte coalesced stores, overlapped with the skinning -- and
+    // the staging buffer plus the device-to-host copy command (~10 us of fixed cost per frame) drop out.
+    // Anything else goes through the staging buffer as before.
+    bool out_direct = false;
     if (out_dev) {
         dp.out_a = a->out_a; dp.out_b = a->out_b;
     } else {
-        HIP_TRY(m->out_a.ensure(bytes_a));
-        if (bytes_b) HIP_TRY(m->out_b.ensure(bytes_b));
-        dp.out_a = m->out_a.ptr; dp.out_b = m->out_b.ptr;
+        void *da = mapped_host_pointer(a->out_a), *db = bytes_b ? mapped_host_pointer(a->out_b) : nullptr;
+        out_direct = da && (!bytes_b || db);
+        if (out_direct) {
+            dp.out_a = da; dp.out_b = db;
+        } else {
+            HIP_TRY(m->out_a.ensure(bytes_a));
+            if (bytes_b) HIP_TRY(m->out_b.ensure(bytes_b));
+            dp.out_a = m->out_a.ptr; dp.out_b = m->out_b.ptr;
+        }
     }
     dp.out_aligned = ((reinterpret_cast<uintptr_t>(dp.out_a) | reinterpret_cast<uintptr_t>(dp.out_b)) & 15) == 0;
 
@@ -490,8 +521,10 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     }
 
     if (!out_dev) {
-        HIP_TRY(hipMemcpyAsync(a->out_a, dp.out_a, bytes_a, hipMemcpyDeviceToHost, st));
-        if (bytes_b) HIP_TRY(hipMemcpyAsync(a->out_b, dp.out_b, bytes_b, hipMemcpyDeviceToHost, st));
+        if (!out_direct) {
+            HIP_TRY(hipMemcpyAsync(a->out_a, dp.out_a, bytes_a, hipMemcpyDeviceToHost, st));
+            if (bytes_b) HIP_TRY(hipMemcpyAsync(a->out_b, dp.out_b, bytes_b, hipMemcpyDeviceToHost, st));
+        }
         HIP_TRY(wait_stream(st));
     } else if (!(a->flags & MMDX_PALETTE_ON_DEVICE) ||
                (morph != kMorphNone && !(a->flags & MMDX_WEIGHTS_ON_DEVICE))) {

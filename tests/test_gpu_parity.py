@@ -287,6 +287,46 @@ def test_device_resident_io_matches_host_io(oracle):
             b.free()
 
 
+@pytest.mark.parametrize("nv", [1, 513, 4099])
+def test_page_locked_host_outputs_are_written_directly(oracle, nv):
+    """Host outputs in page-locked memory (mmdx_host_malloc) take the direct path -- the kernel stores into them
+    over PCIe, no staging copy -- pageable ones the staging path: same bits, for every layout, single and batched
+    calls, and for an output that starts in the middle of the locked allocation at an address that is not 16-byte
+    aligned."""
+    from simple_mmd_renderer_amd.engine import PinnedArray
+    m = synth.make_model(nv, 40, 6, 60, seed=77 + nv)
+    ni = 5
+    rates = synth.morph_weights(m.nm, np.arange(ni) * 3)
+    pals = synth.make_palettes(m, np.arange(ni) * 2)
+    with DeformModel(m) as dm:
+        pos, nrm = dm.deform_batched(rates, pals)                       # pageable numpy outputs: staging
+        v32 = dm.deform_batched(rates, pals, layout=api.OUT_VERTEX32, pos_scale=0.1)
+        for i in range(ni):
+            ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+            gu.assert_bits_equal(pos[i], ep, "staged pos")
+        pa, pb = PinnedArray((ni * nv * 3 + 8,), np.float32), PinnedArray((ni * nv * 3 + 8,), np.float32)
+        pv = PinnedArray((ni * nv * 8 + 8,), np.float32)
+        for off in (0, 1, 3):                                           # floats: 0, 4 and 12 bytes into the allocation
+            pa.array[:] = -7.0
+            pb.array[:] = -7.0
+            pv.array[:] = -7.0
+            dm.deform_batched_raw(ni, rates.ctypes.data, pals.ctypes.data, pa.ptr + 4 * off, pb.ptr + 4 * off, api.OUT_SOA, 0)
+            gu.assert_bits_equal(pa.array[off:off + ni * nv * 3].reshape(ni, nv, 3), pos, f"direct pos, offset {off}")
+            gu.assert_bits_equal(pb.array[off:off + ni * nv * 3].reshape(ni, nv, 3), nrm, f"direct nrm, offset {off}")
+            assert (pa.array[:off] == -7.0).all() and (pa.array[off + ni * nv * 3:] == -7.0).all()   # nothing outside
+            dm.deform_batched_raw(ni, rates.ctypes.data, pals.ctypes.data, pv.ptr + 4 * off, None, api.OUT_VERTEX32, 0, 0.1)
+            gu.assert_bits_equal(pv.array[off:off + ni * nv * 8].reshape(ni, nv, 8), v32, f"direct vertex32, offset {off}")
+            assert (pv.array[:off] == -7.0).all() and (pv.array[off + ni * nv * 8:] == -7.0).all()
+        one = PinnedArray((nv, 8), np.float32)
+        import ctypes as C
+        f32p = C.POINTER(C.c_float)
+        api.check(api.lib().mmdx_deform_vertex32(dm.h, rates[1].ctypes.data_as(f32p), pals[1].ctypes.data_as(f32p),
+                                                 C.c_float(0.1), one.ptr))
+        gu.assert_bits_equal(one.array, v32[1], "single frame, direct")
+        for x in (pa, pb, pv, one):
+            x.free()
+
+
 @pytest.mark.parametrize("nv,layout,tries", [(4096, api.OUT_SOA, 6), (4100, api.OUT_VERTEX32, 6), (1001, api.OUT_SOA, 6),
                                              (4096, api.OUT_SOA, 1), (2048, api.OUT_SOA_POS16, 4)])
 def test_placement_aware_output_alloc(oracle, nv, layout, tries):
