@@ -208,7 +208,8 @@ MMDX_API mmdx_status mmdx_device_free(void *ptr);
  * without the runtime's staging copy, and OUTPUT buffers from here (or any hipHostMalloc / hipHostRegister
  * memory) are written by the kernel directly -- no device-side staging buffer, no device-to-host copy
  * command: the single-model drop-in path (the viewer's vertex buffer, main.cpp:735-863).  Pageable
- * memory works everywhere too, through staging copies. */
+ * memory works everywhere too: frame-sized inputs / outputs go through page-locked bounce buffers owned by
+ * the model (one extra CPU memcpy), larger ones through the runtime's staging copies. */
 MMDX_API mmdx_status mmdx_host_malloc(void **ptr, size_t bytes);
 MMDX_API mmdx_status mmdx_host_free(void *ptr);
 MMDX_API mmdx_status mmdx_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);

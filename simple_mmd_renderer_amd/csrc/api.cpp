@@ -89,6 +89,10 @@ struct mmdx_model_s {
         ell, entries, slot_top, chain_off, chain_rate;
     // per-call scratch (grown on demand, reused)
     DevBuf pal, rates, wslot, morphed, out_a, out_b;
+    // page-locked bounce buffer for small outputs bound for pageable host memory (see mmdx_deform_batched)
+    void *bounce = nullptr;
+    size_t bounce_bytes = 0;
+    void *bounce_in = nullptr;                     // the same for small pageable inputs (palette, rates)
 };
 
 namespace {
@@ -98,9 +102,12 @@ constexpr size_t kMaxProfiledCalls = 1 << 16;
 // The device-side address of a host pointer that lies in page-locked, device-mapped memory; nullptr for
 // pageable memory (and for device memory: callers pass that with the *_ON_DEVICE flags).  MMDX_HOST_DIRECT=0
 // turns the direct path off (A/B against the staging copy).
-void *mapped_host_pointer(const void *host) {
+bool host_direct_enabled() {
     static const bool enabled = [] { const char *e = std::getenv("MMDX_HOST_DIRECT"); return !(e && e[0] == '0'); }();
-    if (!enabled || !host) return nullptr;
+    return enabled;
+}
+void *mapped_host_pointer(const void *host) {
+    if (!host_direct_enabled() || !host) return nullptr;
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, host) != hipSuccess) {
         (void)hipGetLastError();                    // pageable memory: "invalid value", not an error of ours
@@ -113,6 +120,27 @@ void *mapped_host_pointer(const void *host) {
         return nullptr;
     }
     return dev;
+}
+
+// Host-to-device copy of a per-call input.  Small pageable inputs (one frame's palette, its rates) are first
+// copied by the CPU into the model's page-locked bounce buffer -- slot `slot_off` of it, the palette and the rates
+// use different halves -- so the copy command is a plain DMA instead of the runtime's pageable path.  The previous
+// call's copy out of the same slot has completed: every call with host inputs waits on the stream before it returns.
+constexpr size_t kBounceInBytes = size_t(256) << 10;
+hipError_t copy_in(mmdx_model_s *m, void *dst, const void *src, size_t bytes, size_t slot_off, hipStream_t st) {
+    if (!bytes) return hipSuccess;
+    if (bytes <= kBounceInBytes / 2 && host_direct_enabled() && !mapped_host_pointer(src)) {
+        if (!m->bounce_in && hipHostMalloc(&m->bounce_in, kBounceInBytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            m->bounce_in = nullptr;
+        }
+        if (m->bounce_in) {
+            void *slot = static_cast<unsigned char *>(m->bounce_in) + slot_off;
+            std::memcpy(slot, src, bytes);
+            return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st);
+        }
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
 }
 
 int env_int(const char *name, int dflt) {
@@ -154,6 +182,8 @@ void free_model(mmdx_model_s *m) {
                           &m->entries, &m->slot_top, &m->chain_off, &m->chain_rate, &m->pal, &m->rates,
                           &m->wslot, &m->morphed, &m->out_a, &m->out_b})
             b->release();
+        if (m->bounce) (void)hipHostFree(m->bounce);
+        if (m->bounce_in) (void)hipHostFree(m->bounce_in);
         for (hipEvent_t ev : {m->ev_t0, m->ev_t1})
             if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : m->prof_events) (void)hipEventDestroy(ev);
@@ -406,7 +436,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         dp.palettes = a->palettes;
     } else {
         HIP_TRY(m->pal.ensure(pal_bytes));
-        HIP_TRY(hipMemcpyAsync(m->pal.ptr, a->palettes, pal_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(copy_in(m, m->pal.ptr, a->palettes, pal_bytes, 0, st));
         dp.palettes = static_cast<const float *>(m->pal.ptr);
     }
 
@@ -420,8 +450,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
             rates_dev = a->morph_weights;
         } else {
             HIP_TRY(m->rates.ensure(size_t(niw) * p.nm * 4));
-            HIP_TRY(hipMemcpyAsync(m->rates.ptr, a->morph_weights, size_t(niw) * p.nm * 4,
-                                   hipMemcpyHostToDevice, st));
+            HIP_TRY(copy_in(m, m->rates.ptr, a->morph_weights, size_t(niw) * p.nm * 4, kBounceInBytes / 2, st));
             rates_dev = static_cast<const float *>(m->rates.ptr);
         }
         FlattenParams f;
@@ -457,14 +486,32 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // kernel stores straight into them over PCIe -- 16-byte coalesced stores, overlapped with the skinning -- and
     // the staging buffer plus the device-to-host copy command (~10 us of fixed cost per frame) drop out.
     // Anything else goes through the staging buffer as before.
-    bool out_direct = false;
+    // Small outputs bound for pageable memory (a frame of one model) take the same route into a page-locked
+    // bounce buffer of the model's and are copied out by the CPU after the wait: the copy command into pageable
+    // memory is the one piece of the per-frame call whose cost varies by 100 us between hosts.
+    bool out_direct = false, out_bounce = false;
+    constexpr size_t kBounceMax = size_t(4) << 20;
+    const size_t off_b = (bytes_a + 63) & ~size_t(63);
     if (out_dev) {
         dp.out_a = a->out_a; dp.out_b = a->out_b;
     } else {
         void *da = mapped_host_pointer(a->out_a), *db = bytes_b ? mapped_host_pointer(a->out_b) : nullptr;
         out_direct = da && (!bytes_b || db);
-        if (out_direct) {
-            dp.out_a = da; dp.out_b = db;
+        if (!out_direct && off_b + bytes_b <= kBounceMax && host_direct_enabled()) {
+            if (m->bounce_bytes < off_b + bytes_b) {
+                if (m->bounce) (void)hipHostFree(m->bounce);
+                m->bounce = nullptr; m->bounce_bytes = 0;
+                if (hipHostMalloc(&m->bounce, kBounceMax, hipHostMallocDefault) == hipSuccess) m->bounce_bytes = kBounceMax;
+                else (void)hipGetLastError();
+            }
+            if (m->bounce) {
+                da = mapped_host_pointer(m->bounce);
+                out_bounce = da != nullptr;
+                if (out_bounce) db = static_cast<unsigned char *>(da) + off_b;
+            }
+        }
+        if (out_direct || out_bounce) {
+            dp.out_a = da; dp.out_b = bytes_b ? db : nullptr;
         } else {
             HIP_TRY(m->out_a.ensure(bytes_a));
             if (bytes_b) HIP_TRY(m->out_b.ensure(bytes_b));
@@ -521,11 +568,15 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     }
 
     if (!out_dev) {
-        if (!out_direct) {
+        if (!out_direct && !out_bounce) {
             HIP_TRY(hipMemcpyAsync(a->out_a, dp.out_a, bytes_a, hipMemcpyDeviceToHost, st));
             if (bytes_b) HIP_TRY(hipMemcpyAsync(a->out_b, dp.out_b, bytes_b, hipMemcpyDeviceToHost, st));
         }
         HIP_TRY(wait_stream(st));
+        if (out_bounce) {
+            std::memcpy(a->out_a, m->bounce, bytes_a);
+            if (bytes_b) std::memcpy(a->out_b, static_cast<unsigned char *>(m->bounce) + off_b, bytes_b);
+        }
     } else if (!(a->flags & MMDX_PALETTE_ON_DEVICE) ||
                (morph != kMorphNone && !(a->flags & MMDX_WEIGHTS_ON_DEVICE))) {
         // borrowed host inputs must be consumed before we return

@@ -3,6 +3,7 @@ committed under profiles/<round>/:  python tools/summarize_profiles.py gpurun_ou
   config3_kernel_stats.csv        rocprofv3 --kernel-trace --stats (verbatim)
   config3_pmc_hbm_traffic.csv     per-kernel mean/min/max of FETCH_SIZE and WRITE_SIZE (KB as reported,
                                   separate passes); bench.py reads this file for roofline.traffic
+  all_workloads_kernel_stats.csv  the same with bench.py's secondary workloads on: every kernel of the library
   config3_bench.json              the plain bench line of the same box
   config3_bench_under_rocprof.json the line printed while tracing (HIP-event time to compare with the trace)
   config3_kernel_trace_timed_region.csv  per-kernel average over the LAST `steps` dispatches of the trace =
@@ -21,6 +22,8 @@ def main(src, dst):
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(dst, "config3_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "config3_bench.json"))
+    if os.path.exists(os.path.join(src, "kt_all", "all_kernel_stats.csv")):
+        shutil.copy(os.path.join(src, "kt_all", "all_kernel_stats.csv"), os.path.join(dst, "all_workloads_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "config3_bench_under_rocprof.json"))
     steps = json.load(open(os.path.join(src, "bench_under_rocprof.json")))["steps"]
     per = collections.OrderedDict()
