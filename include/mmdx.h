@@ -191,10 +191,14 @@ MMDX_API mmdx_status mmdx_sync(mmdx_model_t model);
 /* ---- timing on the handle's stream (HIP events; for bench harnesses) ------------------------- */
 MMDX_API mmdx_status mmdx_timer_start(mmdx_model_t model);
 MMDX_API mmdx_status mmdx_timer_stop(mmdx_model_t model, float *elapsed_ms); /* syncs the stream  */
-/* Per-kernel timing without perturbing the launch stream: while enabled, every mmdx_deform_batched
- * call records HIP events around its morph kernels and around its skinning kernel (no host sync).
- * mmdx_profile_collect waits for the recorded calls, returns how many there were and the summed
- * milliseconds of the skinning kernel and of the morph pass, and resets the recording. */
+/* Per-kernel timing with no host synchronisation: while enabled, mmdx_deform_batched records HIP events on
+ * the launch stream around its morph kernels and around its skinning kernel -- on every call (enabled == 1)
+ * or on every N-th call (enabled == N > 1): the four event records cost the stream about 7 us per call, which a
+ * throughput measurement should not pay on every step.  (Timing the skinning kernel alone is not offered: its
+ * start event must follow another event record, or it is stamped with the end of the previous KERNEL and the
+ * interval then includes the launch gap.)  mmdx_profile_collect waits for the recorded calls, returns how
+ * many were timed and the summed milliseconds of the skinning kernel and of the morph pass, and resets
+ * the recording. */
 MMDX_API mmdx_status mmdx_profile_enable(mmdx_model_t model, int32_t enabled);
 MMDX_API mmdx_status mmdx_profile_collect(mmdx_model_t model, uint32_t *n_calls, float *skin_ms_total,
                                           float *morph_ms_total);

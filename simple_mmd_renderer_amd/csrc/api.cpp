@@ -83,6 +83,7 @@ struct mmdx_model_s {
     std::vector<uint8_t> prof_has_morph;
     size_t prof_calls = 0;
     bool profile = false;
+    uint32_t profile_stride = 1, prof_seen = 0;     // time every profile_stride-th call
     uint64_t device_bytes = 0;
     // static streams
     DevBuf tiles, spos, snrm, suv, perm, skin1, skin2_ids, skin2_w, skin4_ids, skin4_w, bone_list,
@@ -393,7 +394,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = m->stream;
     hipEvent_t *pev = nullptr;  // {skin0, skin1, morph0, morph1} of this call when profiling
-    if (m->profile) {
+    if (m->profile && m->prof_seen++ % m->profile_stride == 0) {
         if (m->prof_calls >= kMaxProfiledCalls)
             return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_profile: too many calls without mmdx_profile_collect");
         while (m->prof_events.size() < 4 * (m->prof_calls + 1)) {
@@ -636,6 +637,8 @@ mmdx_status mmdx_timer_stop(mmdx_model_t m, float *ms) {
 mmdx_status mmdx_profile_enable(mmdx_model_t m, int32_t enabled) {
     if (!m || m->device < 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
     m->profile = enabled != 0;
+    m->profile_stride = enabled > 1 ? uint32_t(enabled) : 1u;
+    m->prof_seen = 0;
     m->prof_calls = 0;
     return MMDX_OK;
 }

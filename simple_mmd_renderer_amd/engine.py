@@ -288,8 +288,9 @@ class DeformModel:
         api.check(api.lib().mmdx_timer_stop(self.h, C.byref(ms)))
         return float(ms.value)
 
-    def profile_enable(self, on: bool) -> None:
-        api.check(api.lib().mmdx_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, on, every: int = 1) -> None:
+        """Events around the morph kernels and the skinning kernel of every call, or of every `every`-th call."""
+        api.check(api.lib().mmdx_profile_enable(self.h, max(int(every), 1) if on else 0))
 
     def profile_collect(self) -> Tuple[int, float, float]:
         """(calls, skin kernel ms total, morph pass ms total) since profile_enable / last collect."""
