@@ -61,6 +61,13 @@ int main(int argc, char **argv) {
             poser.Deform();                                                   // main.cpp:1821
             poser.UpdateDeformedVertices(vertices);                           // main.cpp:1824 (-> sg_update_buffer)
         }
+        // the same last frame into page-locked storage (written by the kernel directly): identical bytes
+        std::vector<mmdx::Vertex, mmdx::PinnedAllocator<mmdx::Vertex>> pinned;
+        poser.UpdateDeformedVertices(pinned);
+        if (std::memcmp(pinned.data(), vertices.data(), vertices.size() * sizeof(mmdx::Vertex)) != 0) {
+            std::printf("MISMATCH between the page-locked and the pageable vertex buffer\n");
+            return 2;
+        }
         std::printf("frames=%d nv=%u pose_image=%016llx vertices=%016llx\n", frames, nv,
                     (unsigned long long)checksum(poser.pose_image.coordinates.data(), size_t(nv) * 12),
                     (unsigned long long)checksum(vertices.data(), vertices.size() * sizeof(mmdx::Vertex)));

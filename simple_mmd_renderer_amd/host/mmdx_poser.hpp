@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -47,6 +48,27 @@ struct ModelData {
     std::vector<uint32_t> morph_offset, morph_index;      // [NM+1], [E]
     std::vector<float> morph_value;                       // [E][3]
     uint32_t n_vertices = 0, n_bones = 0, n_morphs = 0;
+};
+
+// Page-locked storage for the buffers handed to the deform calls, e.g.
+//   std::vector<Vertex, mmdx::PinnedAllocator<Vertex>> vertices;
+// (the viewer's `vertices` array of main.cpp:735): outputs in such memory are written by the kernel directly.
+template <class T>
+struct PinnedAllocator {
+    using value_type = T;
+    PinnedAllocator() = default;
+    template <class U>
+    PinnedAllocator(const PinnedAllocator<U> &) {}
+    T *allocate(std::size_t n) {
+        void *p = nullptr;
+        if (mmdx_host_malloc(&p, n * sizeof(T)) != MMDX_OK) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, std::size_t) noexcept { (void)mmdx_host_free(p); }
+    template <class U>
+    bool operator==(const PinnedAllocator<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const PinnedAllocator<U> &) const { return false; }
 };
 
 class Poser {
@@ -146,8 +168,11 @@ public:
                           reinterpret_cast<float *>(pose_image.normals.data())));
     }
 
-    // Deform + repack in ONE pass on the GPU: replaces main.cpp:1821 and :1824 together.
-    void UpdateDeformedVertices(std::vector<Vertex> &vertices, float mmd_to_meter = 0.1f) {
+    // Deform + repack in ONE pass on the GPU: replaces main.cpp:1821 and :1824 together.  With a vector on
+    // PinnedAllocator (below) the kernel stores the vertices straight into it; a plain vector goes through the
+    // library's bounce buffer (one extra CPU copy).
+    template <class Alloc>
+    void UpdateDeformedVertices(std::vector<Vertex, Alloc> &vertices, float mmd_to_meter = 0.1f) {
         vertices.resize(nv_);
         check(mmdx_deform_vertex32(model_, morph_rates_.data(), palette_.data(), mmd_to_meter,
                                    vertices.data()));
