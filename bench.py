@@ -175,6 +175,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": deform_bytes, "avg_kernel_ms": skin_avg,
                      "uninstrumented_ms_per_step": plain_ms,
+                     "trailing_steps": args.steps,     # launches after the timed region (for trace post-processing)
                      "step_algorithmic_bytes": step_bytes, "morph_pass_ms": morph_avg,
                      "step_event_ms": ev_ms / args.steps, "output_placement": placement,
                      "settle_batches_kernel_ms": [round(x, 4) for x in settle_batches]},
@@ -199,6 +200,7 @@ def main():
             api.check(api.lib().mmdx_bench_store_pattern(d_a.ptr, d_b.ptr, model.nv, ni, 10, C.byref(ms)))
             result["roofline"]["measured_store_pattern_GBs"] = ni * model.nv * 24 / (ms.value * 1e-3) / 1e9
             step()      # leave real results in the output buffers
+            result["roofline"]["trailing_steps"] += 1
 
     # ---- CPU baseline: rank 0, N=1 only ------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

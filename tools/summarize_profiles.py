@@ -6,9 +6,10 @@ committed under profiles/<round>/:  python tools/summarize_profiles.py gpurun_ou
   all_workloads_kernel_stats.csv  the same with bench.py's secondary workloads on: every kernel of the library
   config3_bench.json              the plain bench line of the same box
   config3_bench_under_rocprof.json the line printed while tracing (HIP-event time to compare with the trace)
-  config3_kernel_trace_timed_region.csv  per-kernel average over the LAST `steps` dispatches of the trace =
-                                  bench.py's timed region (the stats file above also averages the untimed
-                                  settle / warm-up launches, which run through the clock transient)
+  config3_kernel_trace_timed_region.csv  per-kernel average over the `steps` dispatches of bench.py's timed region
+                                  and over the uninstrumented repeat that follows it (the stats file above
+                                  also averages the untimed settle / warm-up launches, which run through the
+                                  clock transient)
 """
 import collections
 import csv
@@ -25,18 +26,21 @@ def main(src, dst):
     if os.path.exists(os.path.join(src, "kt_all", "all_kernel_stats.csv")):
         shutil.copy(os.path.join(src, "kt_all", "all_kernel_stats.csv"), os.path.join(dst, "all_workloads_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "config3_bench_under_rocprof.json"))
-    steps = json.load(open(os.path.join(src, "bench_under_rocprof.json")))["steps"]
+    line = json.load(open(os.path.join(src, "bench_under_rocprof.json")))
+    steps, trailing = line["steps"], line["roofline"].get("trailing_steps", 0)
     per = collections.OrderedDict()
     with open(os.path.join(src, "kt", "kt_kernel_trace.csv"), newline="") as f:
         for r in csv.DictReader(f):
             per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(os.path.join(dst, "config3_kernel_trace_timed_region.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "dispatches_in_trace", "last_n", "avg_ns_last_n", "min_ns_last_n", "max_ns_last_n", "avg_ns_all"])
+        w.writerow(["kernel", "dispatches_in_trace", "timed_n", "avg_ns_timed_region", "min_ns_timed_region",
+                    "max_ns_timed_region", "avg_ns_uninstrumented_repeat", "avg_ns_all"])
         for k, v in per.items():
             if "deform_kernel" in k or "morph_apply" in k:
-                t = v[-steps:]
-                w.writerow([k, len(v), len(t), sum(t) / len(t), min(t), max(t), sum(v) / len(v)])
+                t = v[len(v) - trailing - steps:len(v) - trailing]       # the K launches bracketed by events
+                u = v[len(v) - trailing:len(v) - trailing + steps]      # the same K steps repeated without events
+                w.writerow([k, len(v), len(t), sum(t) / len(t), min(t), max(t), sum(u) / len(u) if u else "", sum(v) / len(v)])
     rows = []
     for counter, path in (("FETCH_SIZE", "pmc_fetch/fetch_counter_collection.csv"),
                           ("WRITE_SIZE", "pmc_write/write_counter_collection.csv")):
