@@ -358,6 +358,30 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     except Exception as e:                                   # pragma: no cover - reporting only
         out["config3_vertex32_output"] = {"error": repr(e)}
 
+    # config 3 "bucketed" (SURVEY 8d): the model with its vertices pre-sorted by deform type inside each tile, so the
+    # class-sorted lanes write their own slots of the output image instead of scattering through a permutation.
+    try:
+        ni = 1024
+        sorted3 = synth.presort_by_class(model3)
+        dms = DeformModel(sorted3)
+        d_w3 = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, 30)[0])
+        d_pal3 = DeviceBuffer.from_numpy(synth.make_palettes(model3, (np.arange(ni) * 3) % 1801))
+        d_as, d_bs, _pl = dms.alloc_outputs(api.OUT_SOA, ni, 32)
+        dms.profile_enable(True)
+        ms_s = time_calls(dms, lambda: dms.deform_batched_raw(ni, d_w3.ptr, d_pal3.ptr, d_as.ptr, d_bs.ptr, api.OUT_SOA,
+                                                              flags_dev | api.WEIGHTS_SHARED), 20)
+        ncalls, skin_ms, _m = dms.profile_collect()
+        dms.profile_enable(False)
+        out["config3_bucketed_vertices"] = {"ms_per_call": ms_s, "vertices_per_s": ni * model3.nv / (ms_s * 1e-3),
+                                            "deform_kernel_ms": skin_ms / ncalls, "placement": _pl,
+                                            "note": "vertices pre-sorted by deform type: same kernel time as file "
+                                                    "order -- the LDS scatter is off the critical path"}
+        for b in (d_w3, d_pal3, d_as, d_bs):
+            b.free()
+        dms.close()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["config3_bucketed_vertices"] = {"error": repr(e)}
+
     # config 3' (SURVEY 8d): the same 1024-instance crowd with PER-INSTANCE morph weights (every instance its
     # own facial state): the fused gather path, 4 instances per pass over a vertex's morph row.
     try:

@@ -201,6 +201,34 @@ CONFIGS = {
 }
 
 
+def presort_by_class(m: FlatModel, tile: int = 512) -> FlatModel:
+    """The same model with its vertices reordered, inside each `tile` consecutive vertices, by deform class
+    (BDEF1, BDEF2/SDEF, BDEF4) and by the number of morph entries that touch them -- the order the plan gives a
+    tile's lanes.  SURVEY 8d's "bucketed" variant: the engine's lane -> output permutation becomes the identity."""
+    st = np.asarray(m.skin_type)
+    cls = np.where(st == BDEF1, 0, np.where(st == BDEF4, 2, 1))
+    vm = np.concatenate([np.asarray(m.morph_index[int(m.morph_off[k]):int(m.morph_off[k + 1])], np.int64)
+                         for k in range(m.nm) if int(m.morph_type[k]) == MORPH_VERTEX] or [np.zeros(0, np.int64)])
+    cnt = np.bincount(vm, minlength=m.nv)
+    order = np.concatenate([vs[np.lexsort((vs, -cnt[vs], cls[vs]))]
+                            for vs in (np.arange(t0, min(t0 + tile, m.nv)) for t0 in range(0, m.nv, tile))])
+    new_of = np.empty(m.nv, np.int64)
+    new_of[order] = np.arange(m.nv)
+    s = m.copy()
+    for f in ("positions", "normals", "uvs", "skin_type", "bone_ids", "bone_weights"):
+        setattr(s, f, np.ascontiguousarray(getattr(m, f)[order]))
+    if m.sdef is not None:
+        s.sdef = np.ascontiguousarray(m.sdef[order])
+    idx = np.asarray(m.morph_index).copy()
+    for k in range(m.nm):
+        if int(m.morph_type[k]) == MORPH_VERTEX:
+            lo, hi = int(m.morph_off[k]), int(m.morph_off[k + 1])
+            idx[lo:hi] = new_of[idx[lo:hi]]
+    s.morph_index = idx.astype(np.uint32)
+    s.meta = dict(m.meta, presorted=True)
+    return s
+
+
 def make_config(name: str) -> FlatModel:
     c = CONFIGS[name]
     m = make_model(c["nv"], c["nb"], c["nm"], c["k"], c["seed"])

@@ -287,6 +287,20 @@ def test_device_resident_io_matches_host_io(oracle):
             b.free()
 
 
+def test_bucketed_model_matches_oracle(oracle):
+    """SURVEY 8d's "bucketed" variant: vertices pre-sorted by deform type inside each tile (synth.presort_by_class)
+    -- another model as far as parity goes, the identity lane -> output permutation as far as the kernel goes."""
+    m = synth.presort_by_class(synth.make_model(3001, 70, 9, 300, seed=91))
+    rates = synth.morph_weights(m.nm, np.arange(3) * 5)
+    pals = synth.make_palettes(m, np.arange(3))
+    with DeformModel(m) as dm:
+        pos, nrm = dm.deform_batched(rates, pals)
+        for i in range(3):
+            ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+            gu.assert_bits_equal(pos[i], ep, "pos")
+            gu.assert_bits_equal(nrm[i], en, "nrm")
+
+
 @pytest.mark.parametrize("nv", [1, 513, 4099])
 def test_page_locked_host_outputs_are_written_directly(oracle, nv):
     """Host outputs in page-locked memory (mmdx_host_malloc) take the direct path -- the kernel stores into them

@@ -158,3 +158,20 @@ def test_large_config_plans_build():
     assert i.n_entries == 200 * 2048
     assert i.max_tile_bones <= 64     # 16-wide bone window + drift across a 512-vertex tile
     dm.close()
+
+
+def test_presort_by_class_is_a_vertex_permutation(oracle):
+    """synth.presort_by_class (the "bucketed" bench variant) only reorders vertices: the oracle's deformed vertices
+    of the reordered model are the original's, permuted."""
+    m = synth.make_model(2500, 40, 8, 200, seed=5)
+    s = synth.presort_by_class(m)
+    assert s.nv == m.nv and s.meta.get("presorted")
+    rates = synth.morph_weights(m.nm, 11)[0]
+    pal = synth.make_palettes(m, [3])[0]
+    pa, na = oracle.skin(m, pal, oracle.morph(m, rates), oracle.normalize(m))
+    pb, nb = oracle.skin(s, pal, oracle.morph(s, rates), oracle.normalize(s))
+    key = lambda p, n: np.sort(np.concatenate([p, n], 1).view(np.uint32).view([("", np.uint32)] * 6).ravel())
+    assert np.array_equal(key(pa, na), key(pb, nb))
+    st = np.asarray(s.skin_type)[:512]
+    cls = np.where(st == synth.BDEF1, 0, np.where(st == synth.BDEF4, 2, 1))
+    assert (np.diff(cls) >= 0).all()                      # first tile: classes in order

@@ -7,9 +7,12 @@ N configurations x R rounds, median and min of the HIP-event kernel time per con
 Each argument is a space-separated list of VAR=VALUE settings read by libmmdx at call time
 (MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET, and MMDX_ABLATE in ablation builds).
 Workload: BASELINE config 3 (1024 x 50k crowd, shared morphs), override with AB_WORKLOAD=v32.
+AB_DENSE=1: no events, wall clock per whole step (morph pass + deform kernel back to back) instead of the
+event-bracketed deform kernel.
 """
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -35,7 +38,8 @@ def main():
     d_a, d_b, placement = dm.alloc_outputs(layout, ni, 24)     # fast placement mode
     print("output placement:", placement, flush=True)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
-    dm.profile_enable(True)
+    dense = os.environ.get("AB_DENSE") == "1"
+    dm.profile_enable(not dense)
     res = [[] for _ in cfgs]
     warm = int(os.environ.get("AB_WARM_ROUNDS", "3"))               # clock transient after idle: ~100 launches
     for r in range(rounds + warm):
@@ -43,9 +47,20 @@ def main():
             for k in KNOBS:
                 os.environ.pop(k, None)
             os.environ.update(cfg)
-            for _ in range(iters):                  # back-to-back, no host sync: sustained rate
-                dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout,
-                                      flags, 0.1 if layout == api.OUT_VERTEX32 else 1.0)
+            def burst(n_):
+                for _ in range(n_):                 # back-to-back, no host sync: sustained rate
+                    dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout,
+                                          flags, 0.1 if layout == api.OUT_VERTEX32 else 1.0)
+            if dense:       # no events at all: wall clock per step (kernels back to back)
+                burst(5)
+                dm.sync()
+                t0 = time.perf_counter()
+                burst(iters * 10)
+                dm.sync()
+                if r >= warm:
+                    res[ci].append((time.perf_counter() - t0) / (iters * 10) * 1e3)
+                continue
+            burst(iters)
             n, skin, _ = dm.profile_collect()
             if r >= warm:
                 res[ci].append(skin / n)

@@ -14,33 +14,13 @@ from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
 
 
-def presorted(m, tile=512):
-    st = np.asarray(m.skin_type)
-    cls = np.where(st == 0, 0, np.where(st == 2, 2, 1))
-    cnt = np.bincount(np.asarray(m.morph_index), minlength=m.nv)
-    order = []
-    for t0 in range(0, m.nv, tile):
-        vs = np.arange(t0, min(t0 + tile, m.nv))
-        order.append(vs[np.lexsort((vs, -cnt[vs], cls[vs]))])
-    order = np.concatenate(order)
-    new_of = np.empty(m.nv, np.int64)
-    new_of[order] = np.arange(m.nv)
-    s = m.copy()
-    for f in ("positions", "normals", "uvs", "skin_type", "bone_ids", "bone_weights"):
-        setattr(s, f, np.ascontiguousarray(getattr(m, f)[order]))
-    if m.sdef is not None:
-        s.sdef = np.ascontiguousarray(m.sdef[order])
-    s.morph_index = new_of[np.asarray(m.morph_index)].astype(np.uint32)
-    return s
-
-
 def main():
     rounds, iters, warm = 7, 10, 3
     model = synth.make_config("config3_crowd")
     ni = 1024
     pals = synth.make_palettes(model, (np.arange(ni) * 3) % 1801)
     rates = synth.morph_weights(model.nm, 30)[0]
-    dms = [("file order (random scatter)", DeformModel(model)), ("pre-sorted (identity scatter)", DeformModel(presorted(model)))]
+    dms = [("file order (random scatter)", DeformModel(model)), ("pre-sorted (identity scatter)", DeformModel(synth.presort_by_class(model)))]
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
     d_a, d_b, placement = dms[0][1].alloc_outputs(api.OUT_SOA, ni, 24)
     print("output placement:", placement, flush=True)
