@@ -15,7 +15,7 @@ model = synth.make_config("config2_50k")
 dm = DeformModel(model)
 out = bench.extras(api, synth, DeformModel, DeviceBuffer, dm, model)
 for k, v in out.items():
-    if "ms_per_call" in v:
+    if "ms_per_call" in v and "algorithmic_GBs" in v:
         print(f"{k:36s} {v['ms_per_call'] * 1e3:9.1f} us  {v['vertices_per_s'] / 1e9:8.2f} Gverts/s  "
               f"{v['algorithmic_GBs']:8.0f} GB/s")
     else:
