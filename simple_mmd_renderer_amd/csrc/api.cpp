@@ -91,7 +91,7 @@ struct mmdx_model_s {
     // per-call scratch (grown on demand, reused)
     DevBuf pal, rates, wslot, morphed, out_a, out_b;
     // page-locked bounce buffer for small outputs bound for pageable host memory (see mmdx_deform_batched)
-    void *bounce = nullptr;
+    void *bounce = nullptr, *bounce_dev = nullptr;  // host address, device-side address
     size_t bounce_bytes = 0;
     void *bounce_in = nullptr;                     // the same for small pageable inputs (palette, rates)
 };
@@ -107,19 +107,30 @@ bool host_direct_enabled() {
     static const bool enabled = [] { const char *e = std::getenv("MMDX_HOST_DIRECT"); return !(e && e[0] == '0'); }();
     return enabled;
 }
-void *mapped_host_pointer(const void *host) {
-    if (!host_direct_enabled() || !host) return nullptr;
+// What a pointer handed over WITHOUT an *_ON_DEVICE flag is: pageable host memory (unknown to the runtime),
+// page-locked host memory (`*mapped` = its device-side address; interior pointers are fine, the offset carries
+// over), or device memory -- a caller's mistake that must not reach a CPU memcpy.
+enum class PtrKind { Pageable, Mapped, Device };
+PtrKind classify_pointer(const void *p, void **mapped) {
+    *mapped = nullptr;
     hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, host) != hipSuccess) {
+    if (!p || hipPointerGetAttributes(&attr, p) != hipSuccess) {
         (void)hipGetLastError();                    // pageable memory: "invalid value", not an error of ours
-        return nullptr;
+        return PtrKind::Pageable;
     }
-    if (attr.type != hipMemoryTypeHost) return nullptr;
-    void *dev = nullptr;                            // interior pointers are fine: the offset carries over
-    if (hipHostGetDevicePointer(&dev, const_cast<void *>(host), 0) != hipSuccess) {
+    if (attr.type == hipMemoryTypeDevice) return PtrKind::Device;
+    if (attr.type != hipMemoryTypeHost) return PtrKind::Pageable;
+    if (hipHostGetDevicePointer(mapped, const_cast<void *>(p), 0) != hipSuccess) {
         (void)hipGetLastError();
-        return nullptr;
+        *mapped = nullptr;
+        return PtrKind::Pageable;
     }
+    return PtrKind::Mapped;
+}
+void *mapped_host_pointer(const void *host) {
+    void *dev = nullptr;
+    if (!host_direct_enabled()) return nullptr;
+    (void)classify_pointer(host, &dev);
     return dev;
 }
 
@@ -128,9 +139,10 @@ void *mapped_host_pointer(const void *host) {
 // use different halves -- so the copy command is a plain DMA instead of the runtime's pageable path.  The previous
 // call's copy out of the same slot has completed: every call with host inputs waits on the stream before it returns.
 constexpr size_t kBounceInBytes = size_t(256) << 10;
-hipError_t copy_in(mmdx_model_s *m, void *dst, const void *src, size_t bytes, size_t slot_off, hipStream_t st) {
+hipError_t copy_in(mmdx_model_s *m, void *dst, const void *src, PtrKind kind, size_t bytes, size_t slot_off,
+                   hipStream_t st) {
     if (!bytes) return hipSuccess;
-    if (bytes <= kBounceInBytes / 2 && host_direct_enabled() && !mapped_host_pointer(src)) {
+    if (bytes <= kBounceInBytes / 2 && host_direct_enabled() && kind == PtrKind::Pageable) {
         if (!m->bounce_in && hipHostMalloc(&m->bounce_in, kBounceInBytes, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             m->bounce_in = nullptr;
@@ -389,6 +401,22 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     if (!a->palettes || !a->out_a || (layout != MMDX_OUT_VERTEX32 && !a->out_b))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "palettes / out_a / out_b is NULL");
     if (p.ns && !a->morph_weights) return fail(MMDX_ERR_INVALID_ARGUMENT, "morph_weights is NULL");
+    // host arguments: what kind of memory they are (device memory without its *_ON_DEVICE flag is a caller's
+    // mistake that would otherwise end in a CPU memcpy from / to a device address)
+    void *map_a = nullptr, *map_b = nullptr, *map_unused = nullptr;
+    PtrKind kind_pal = PtrKind::Pageable, kind_w = PtrKind::Pageable, kind_a = PtrKind::Pageable, kind_b = PtrKind::Pageable;
+    if (!(a->flags & MMDX_PALETTE_ON_DEVICE) && (kind_pal = classify_pointer(a->palettes, &map_unused)) == PtrKind::Device)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "palettes points to device memory: pass MMDX_PALETTE_ON_DEVICE");
+    if (p.ns && !(a->flags & MMDX_WEIGHTS_ON_DEVICE) &&
+        (kind_w = classify_pointer(a->morph_weights, &map_unused)) == PtrKind::Device)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "morph_weights points to device memory: pass MMDX_WEIGHTS_ON_DEVICE");
+    if (!(a->flags & MMDX_OUT_ON_DEVICE)) {
+        kind_a = classify_pointer(a->out_a, &map_a);
+        if (layout != MMDX_OUT_VERTEX32) kind_b = classify_pointer(a->out_b, &map_b);
+        if (kind_a == PtrKind::Device || kind_b == PtrKind::Device)
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "out_a / out_b points to device memory: pass MMDX_OUT_ON_DEVICE");
+        if (!host_direct_enabled()) map_a = map_b = nullptr;
+    }
     const bool shared = (a->flags & MMDX_WEIGHTS_SHARED) != 0 || ni == 1;
     const uint64_t nvi = uint64_t(ni) * p.nv;
     HIP_TRY(hipSetDevice(m->device));
@@ -437,7 +465,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         dp.palettes = a->palettes;
     } else {
         HIP_TRY(m->pal.ensure(pal_bytes));
-        HIP_TRY(copy_in(m, m->pal.ptr, a->palettes, pal_bytes, 0, st));
+        HIP_TRY(copy_in(m, m->pal.ptr, a->palettes, kind_pal, pal_bytes, 0, st));
         dp.palettes = static_cast<const float *>(m->pal.ptr);
     }
 
@@ -451,7 +479,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
             rates_dev = a->morph_weights;
         } else {
             HIP_TRY(m->rates.ensure(size_t(niw) * p.nm * 4));
-            HIP_TRY(copy_in(m, m->rates.ptr, a->morph_weights, size_t(niw) * p.nm * 4, kBounceInBytes / 2, st));
+            HIP_TRY(copy_in(m, m->rates.ptr, a->morph_weights, kind_w, size_t(niw) * p.nm * 4, kBounceInBytes / 2, st));
             rates_dev = static_cast<const float *>(m->rates.ptr);
         }
         FlattenParams f;
@@ -496,17 +524,18 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     if (out_dev) {
         dp.out_a = a->out_a; dp.out_b = a->out_b;
     } else {
-        void *da = mapped_host_pointer(a->out_a), *db = bytes_b ? mapped_host_pointer(a->out_b) : nullptr;
+        void *da = map_a, *db = bytes_b ? map_b : nullptr;
         out_direct = da && (!bytes_b || db);
         if (!out_direct && off_b + bytes_b <= kBounceMax && host_direct_enabled()) {
             if (m->bounce_bytes < off_b + bytes_b) {
                 if (m->bounce) (void)hipHostFree(m->bounce);
-                m->bounce = nullptr; m->bounce_bytes = 0;
+                m->bounce = nullptr; m->bounce_bytes = 0; m->bounce_dev = nullptr;
                 if (hipHostMalloc(&m->bounce, kBounceMax, hipHostMallocDefault) == hipSuccess) m->bounce_bytes = kBounceMax;
                 else (void)hipGetLastError();
             }
             if (m->bounce) {
-                da = mapped_host_pointer(m->bounce);
+                if (!m->bounce_dev) m->bounce_dev = mapped_host_pointer(m->bounce);
+                da = m->bounce_dev;
                 out_bounce = da != nullptr;
                 if (out_bounce) db = static_cast<unsigned char *>(da) + off_b;
             }

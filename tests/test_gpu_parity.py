@@ -287,6 +287,25 @@ def test_device_resident_io_matches_host_io(oracle):
             b.free()
 
 
+def test_device_pointers_without_their_flag_are_rejected():
+    """Device memory passed as if it were host memory (a missing *_ON_DEVICE flag) fails with a message instead of
+    reaching a CPU memcpy."""
+    m = synth.make_model(700, 20, 4, 30, seed=3)
+    rates = synth.morph_weights(m.nm, 1)[0]
+    pal = synth.make_palettes(m, [0])[0]
+    out_a, out_b = np.empty((m.nv, 3), np.float32), np.empty((m.nv, 3), np.float32)
+    with DeformModel(m) as dm:
+        d_pal, d_w, d_a = DeviceBuffer.from_numpy(pal), DeviceBuffer.from_numpy(rates), DeviceBuffer(m.nv * 12)
+        for kw, frag in ((dict(pal=d_pal.ptr), "MMDX_PALETTE_ON_DEVICE"), (dict(w=d_w.ptr), "MMDX_WEIGHTS_ON_DEVICE"),
+                         (dict(a=d_a.ptr), "MMDX_OUT_ON_DEVICE")):
+            with pytest.raises(api.MmdxError) as e:
+                dm.deform_batched_raw(1, kw.get("w", rates.ctypes.data), kw.get("pal", pal.ctypes.data),
+                                      kw.get("a", out_a.ctypes.data), out_b.ctypes.data, api.OUT_SOA, 0)
+            assert e.value.status == 1 and frag in str(e.value)
+        for b in (d_pal, d_w, d_a):
+            b.free()
+
+
 def test_bucketed_model_matches_oracle(oracle):
     """SURVEY 8d's "bucketed" variant: vertices pre-sorted by deform type inside each tile (synth.presort_by_class)
     -- another model as far as parity goes, the identity lane -> output permutation as far as the kernel goes."""
