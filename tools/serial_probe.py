@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where the serial bone solver's time goes: the same 300-bone rig with (a) no IK / append (parallel FK),
-(b) one append bone (serial sweep, no IK), (c) 8 IK chains with loop counts capped at 0 / 3 / 40 / 256."""
+"""Where the ordered bone solver's time goes: the same 300-bone rig with (a) no IK / append (parallel FK),
+(b) one append bone (ordered solver, no IK), (c) 8 IK chains with loop counts capped at 0 / 3 / 40 / 256.
+(The labels say "serial": the solver's ABI name, MMDX_SOLVER_SERIAL.)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
