@@ -334,6 +334,7 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
                                            "frac_of_8TBs": b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     for b in (d_pal, d_w, d_a, d_b):
         b.free()
+    cpu_reference_frame(out["config2_single_frame"], model3, rates, pals)
 
     # config 3 with the viewer's interleaved 32-byte vertex as output (SURVEY 8d asks for it next to SoA):
     # positions x 0.1, normals, uv passthrough -- Deform + UpdateDeformedVertices in one kernel.
@@ -602,7 +603,23 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     for b in (d_pal, d_w, d_a, d_b):
         b.free()
     dm5.close()
+    cpu_reference_frame(out["config5_single_frame_fp16"], m5, rates, pals)
     return out
+
+
+def cpu_reference_frame(entry, model, rates, pals, nframes=4):
+    """libmmd's whole frame (ResetPosing, SetMorphPose x NM, Pre/PostPhysicsPosing, Deform, 32-byte repack), one
+    thread, f32, next to a single-model GPU figure."""
+    try:
+        from oracle.pyoracle import Reference, reference_available   # checker, CPU leg only
+        if reference_available():
+            ref = Reference(model, normalize=True)
+            secs = ref.time_frames(rates[:nframes], pals[:nframes]) / nframes
+            ref.close()
+            entry["cpu_reference_ms_per_frame"] = secs * 1e3
+            entry["cpu_reference_vertices_per_s"] = model.nv / secs
+    except Exception as e:                                   # pragma: no cover - reporting only
+        entry["cpu_error"] = repr(e)
 
 
 if __name__ == "__main__":
