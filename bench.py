@@ -119,6 +119,13 @@ def main():
             if len(settle_batches) >= 3 and all(abs(settle_batches[-k] / settle_batches[-k - 1] - 1) < 0.015 for k in (1, 2)):
                 break
         dm.profile_enable(False)
+    # ranks settle in different numbers of batches: whoever is done keeps stepping until all are, so that no GPU
+    # idles (and drops its clocks) at the barrier in front of the timed region
+    def keep_busy():
+        for _ in range(5):
+            step()
+        device_synchronize()
+    rv.barrier_while(keep_busy)
     for _ in range(args.warmup):
         step()
     device_synchronize()

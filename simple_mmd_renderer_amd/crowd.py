@@ -58,6 +58,20 @@ class Rendezvous:
         if self._dist is not None:
             self._dist.barrier()
 
+    def barrier_while(self, busy) -> int:
+        """A barrier during which this rank keeps calling busy() (e.g. a few untimed steps) until every rank has
+        arrived: ranks that finish their set-up early do not let their GPU idle -- and drop its clocks -- right
+        before a timed region.  Returns how often busy() ran."""
+        if self._dist is None:
+            return 0
+        work = self._dist.barrier(async_op=True)
+        n = 0
+        while not work.is_completed():
+            busy()
+            n += 1
+        work.wait()
+        return n
+
     def max(self, value: float) -> float:
         if self._dist is None:
             return float(value)
