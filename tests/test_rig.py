@@ -596,3 +596,44 @@ def test_gpu_long_ik_chains(oracle, n_links):
         gu.assert_bits_equal_or_both_nan(got[i], want, f"instance {i}")
         moved += int(not np.array_equal(want, oracle.bone_solve(rest, parent, poses[i])))
     assert moved > 60                                    # the chains really bend
+
+
+@pytest.mark.gpu
+def test_gpu_many_long_chains_share_a_round(oracle):
+    """Eight independent 6-link chains: all of them fit one round, each on its own LDS window -- 95 KB of dynamic
+    LDS, past the 64 KB a kernel gets without asking -- and the result is the oracle's."""
+    n_chains, seg, n_links = 8, 10, 6
+    nb = n_chains * seg
+    rest = np.zeros((nb, 3), np.float32)
+    parent = np.full(nb, -1, np.int32)
+    flags = np.zeros(nb, np.uint16)
+    ik = dict(target=np.full(nb, -1, np.int32), loop=np.zeros(nb, np.int32), angle=np.zeros(nb, np.float32),
+              link_off=np.zeros(nb + 1, np.uint32), link_bone=[], link_limited=[], link_lo=[], link_hi=[])
+    for c in range(n_chains):
+        base = c * seg
+        for k in range(seg - 1):                               # a line base .. base+8
+            rest[base + k] = (c * 2.0, 0.1 * k, 0.0)
+            parent[base + k] = base + k - 1 if k else -1
+        ikb, tgt = base + seg - 1, base + seg - 2
+        parent[ikb] = base
+        rest[ikb] = rest[tgt] + np.float32(0.05)
+        flags[ikb] = 0x20
+        ik["target"][ikb], ik["loop"][ikb], ik["angle"][ikb] = tgt, 10 + c, 1.0
+        links = list(range(tgt - 1, tgt - 1 - n_links, -1))
+        ik["link_bone"] += links
+        ik["link_limited"] += [c % 2] * n_links
+        ik["link_lo"] += [[-1.0, -0.5, 0.0]] * n_links
+        ik["link_hi"] += [[1.0, 0.5, 0.0]] * n_links
+        ik["link_off"][ikb + 1:] = len(ik["link_bone"])
+    ik = dict(ik, link_bone=np.asarray(ik["link_bone"], np.int32), link_limited=np.asarray(ik["link_limited"], np.uint8),
+              link_lo=np.asarray(ik["link_lo"], np.float32), link_hi=np.asarray(ik["link_hi"], np.float32))
+    sk = vmd.Skeleton(rest, parent, None, flags, None, None, ik)
+    assert sk.info["n_ik_bones"] == n_chains and sk.info["n_solve_rounds"] <= seg + 1   # the chains run side by side
+    rng = np.random.RandomState(5)
+    poses = np.zeros((40, nb, 8), np.float32)
+    poses[..., 7] = 1
+    poses[:, flags == 0x20, 0:3] = rng.uniform(-1, 1, (40, n_chains, 3))
+    got = sk.solve(poses)
+    for i in range(40):
+        want = oracle.bone_solve_full(rest, parent, poses[i], None, flags, None, None, ik)
+        gu.assert_bits_equal_or_both_nan(got[i], want, f"instance {i}")
