@@ -94,7 +94,7 @@ def main():
     # pattern depends on where the driver puts the arrays (bimodal); set-up work,
     # outside the timed region, and done first: the big arrays of a young process land in the fast mode
     # within a try or two (tools/shop_probe.py).  --plain-alloc takes whatever hipMalloc hands out first.
-    d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else 64)
+    d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else 128)
     d_pal = DeviceBuffer.from_numpy(pals)
     d_w = DeviceBuffer.from_numpy(rates)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
