@@ -637,3 +637,19 @@ def test_gpu_many_long_chains_share_a_round(oracle):
     for i in range(40):
         want = oracle.bone_solve_full(rest, parent, poses[i], None, flags, None, None, ik)
         gu.assert_bits_equal_or_both_nan(got[i], want, f"instance {i}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_ik,n_app", [(11, 16, 20), (12, 4, 40), (13, 24, 0)])
+def test_gpu_dense_rigs_with_levels_and_post_physics(oracle, seed, n_ik, n_app):
+    """300-bone rigs dense with IK chains / append bones, three transform levels and 30 % post-physics bones (both
+    evaluation lists populated, dependencies across them), 200 instances (the last workgroup partly empty)."""
+    nb, ni = 300, 200
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, seed, n_ik=n_ik, n_append=n_app, post_physics=0.3, levels=3)
+    sk = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik)
+    assert sk.info["n_post_physics"] > 0 and sk.info["n_solve_rounds"] < nb
+    poses = random_poses(ni, nb, 700 + seed)
+    got = sk.solve(poses)
+    for i in range(ni):
+        want = oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, ik)
+        gu.assert_bits_equal_or_both_nan(got[i], want, f"instance {i}")
