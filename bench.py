@@ -215,7 +215,7 @@ def main():
     # ---- CPU baseline: rank 0, N=1 only ------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.pyoracle import Oracle, Reference, reference_available   # checker, CPU leg only
-        reps = 8
+        reps = 24                                   # ~11 s of single-thread CPU work
         if reference_available():
             ref = Reference(model, normalize=True)
             secs = sum(ref.time_crowd(rates, pals) for _ in range(reps))
