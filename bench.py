@@ -41,6 +41,35 @@ def algorithmic_bytes_config3(nv, nb, nm, ne, ni, n1, n2, n4):
     return deform, deform + morph
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: THIS process never loads the product library or touches
+    the GPU; it starts N fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, exactly what torch.distributed.run would hand them), relays rank 0's JSON line and returns the
+    first non-zero exit code.  Never a re-exec of a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return bad[0] if bad[0] > 0 else 1
+    return 0 if lines else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,13 +80,33 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--plain-alloc", action="store_true", help="plain hipMalloc for the output arrays")
+    ap.add_argument("--shop-alloc", type=int, default=128, metavar="TRIES",
+                    help="let mmdx_crowd_output_alloc try up to TRIES placements of the output arrays")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle batches before the warm-up")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous, sharding and the JSON line only -- no GPU work (CPU test of the N>1 plumbing)")
     args = ap.parse_args()
+
+    # N > 1 without a launcher: decided before the product library is loaded or any HIP call is made.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    from simple_mmd_renderer_amd.crowd import Rendezvous, crowd_frames, shard_instances
+    if args.dry_run:
+        rv = Rendezvous()
+        lo, hi = shard_instances(args.instances_per_gpu * rv.world, rv.world, rv.rank)
+        rv.barrier()
+        covered = rv.sum(hi - lo)
+        ranges = rv.gather_u64([lo, hi])
+        rv.close()
+        if rv.rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": rv.world, "instances": int(covered), "ranges": ranges,
+                              "steps": args.steps, "warmup": args.warmup, "scaling": "weak"}))
+        return
 
     # The product library first (it binds the HIP runtime at load); torch only for rendezvous.
     from simple_mmd_renderer_amd import _capi as api
     from simple_mmd_renderer_amd import build, synth
-    from simple_mmd_renderer_amd.crowd import Rendezvous, crowd_frames, shard_instances
     from simple_mmd_renderer_amd.engine import (DeformModel, DeviceBuffer, device_count, device_name,
                                                 device_select, device_synchronize)
     build.build()
@@ -73,10 +122,7 @@ def main():
     DeviceBuffer(256).free()
     rv = Rendezvous()
     rank, world = rv.rank, rv.world
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world           # under a launcher the world size is the launcher's
     barrier = rv.barrier
 
     # ---- workload ------------------------------------------------------------------------------
@@ -94,7 +140,7 @@ def main():
     # pattern depends on where the driver puts the arrays (bimodal); set-up work,
     # outside the timed region, and done first: the big arrays of a young process land in the fast mode
     # within a try or two (tools/shop_probe.py).  --plain-alloc takes whatever hipMalloc hands out first.
-    d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else 128)
+    d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else args.shop_alloc)
     d_pal = DeviceBuffer.from_numpy(pals)
     d_w = DeviceBuffer.from_numpy(rates)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
@@ -103,25 +149,31 @@ def main():
         dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout, flags,
                               pos_scale)
 
-    # Settle: the first ~100 launches after an idle period run through a clock / power transient (kernel
-    # time overshoots by 10-25 % around launch 10-30 and decays; tools/alloc_kernel_probe.py), so a 50-step
-    # measurement taken cold reports the transient, not the sustained rate.  Untimed batches of 20 steps
-    # until two consecutive batches agree within 1.5 % and stop improving (at most 600 steps, ~0.15 s), then the contract's
+    def kernel_only_step():                 # the deform kernel alone: the morphed positions of the last step are reused
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout,
+                              flags | api.MORPH_UNCHANGED, pos_scale)
+
+    def timed_batch(fn, n):
+        """n back-to-back calls bracketed by ONE pair of HIP events on the launch stream; ms per call."""
+        dm.timer_start()
+        for _ in range(n):
+            fn()
+        return dm.timer_stop() / n
+
+    # Settle: the first ~100 launches after an idle period run through a clock / power transient (step time
+    # overshoots by 10-25 % around launch 10-30 and decays; tools/alloc_kernel_probe.py), so a 50-step
+    # measurement taken cold reports the transient, not the sustained rate.  Untimed batches of 20 steps until two
+    # consecutive batches agree within 1.5 % and stop improving (at most 600 steps, ~0.15 s), then the contract's
     # W warm-up steps and the K timed steps.
     settle_batches = []
     if not args.no_settle:
-        dm.profile_enable(True)
         for _ in range(30):
-            for _ in range(20):
-                step()
-            n_, skin_, _m = dm.profile_collect()
-            settle_batches.append(skin_ / n_)
+            settle_batches.append(timed_batch(step, 20))
             # settled = two consecutive batches within 1.5 % of their predecessors AND no longer improving (the
             # transient decays monotonically; a new batch that still beats every earlier one by 0.5 % is its tail)
             if (len(settle_batches) >= 3 and all(abs(settle_batches[-k] / settle_batches[-k - 1] - 1) < 0.015 for k in (1, 2))
                     and settle_batches[-1] > 0.995 * min(settle_batches[:-1])):
                 break
-        dm.profile_enable(False)
     # ranks settle in different numbers of batches: whoever is done keeps stepping until all are, so that no GPU
     # idles (and drops its clocks) at the barrier in front of the timed region
     def keep_busy():
@@ -132,14 +184,11 @@ def main():
     for _ in range(args.warmup):
         step()
     device_synchronize()
-    # HIP events around every kernel launch of the timed region, recorded on the launch stream with no host
-    # synchronisation (read back afterwards): the per-kernel durations ARE the timed region's.  The records are
-    # not free -- each opens a ~10 us bubble on the stream (rocprofv3 trace of tools/event_overhead_probe.py), a
-    # bubble in which the previous kernel's stores drain, so the instrumented step is ~5 % longer and the kernel
-    # inside it ~4 % shorter than in an uninstrumented stream; the same K steps are therefore repeated without
-    # events right after the timed region and reported as roofline.uninstrumented_ms_per_step.
-    every = 1
-    dm.profile_enable(True, every=every)
+    # ---- the timed region: K whole steps, back to back, nothing else on the stream -----------------------------
+    # One HIP event before the first launch and one after the last (on the launch stream) plus the host's wall clock
+    # around barrier + synchronize.  No per-kernel events in here: round 1 showed that each event record opens a
+    # ~10 us bubble on the stream in which the previous kernel's stores drain, which makes the step ~5 % longer and
+    # the kernel inside it ~4 % SHORTER than in the stream a user runs (profiles/r01/event_overhead_trace.txt).
     barrier()
     t0 = time.perf_counter()
     dm.timer_start()
@@ -149,31 +198,34 @@ def main():
     device_synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    ncalls, skin_total, morph_total = dm.profile_collect()
-    dm.profile_enable(False)
-    assert ncalls == (args.steps + every - 1) // every
-    t1 = time.perf_counter()
+    elapsed = rv.max(elapsed)
+    # ---- the dominant kernel, live: K back-to-back launches of the deform kernel ALONE between two HIP events on
+    # its stream (MMDX_MORPH_UNCHANGED: the shared morph state did not change, the morph pass is skipped) -- the
+    # kernel's duration in an uninstrumented stream, which is what a rocprofv3 kernel trace of this run shows too.
+    kernel_ms = timed_batch(kernel_only_step, args.steps)
+    # ---- the old figure, kept as a named extra: events around every kernel of K more steps ---------------------
+    dm.profile_enable(True)
     for _ in range(args.steps):
         step()
-    device_synchronize()
-    plain_ms = rv.max(time.perf_counter() - t1) / args.steps * 1e3
+    ncalls, skin_total, morph_total = dm.profile_collect()
+    dm.profile_enable(False)
     skin_avg = skin_total / ncalls
     morph_avg = morph_total / ncalls
-    elapsed = rv.max(elapsed)
 
     total_vertices = float(ni) * world * model.nv * args.steps
     value = total_vertices / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
     deform_bytes, step_bytes = algorithmic_bytes_config3(model.nv, model.nb, model.nm, info.n_entries, ni,
                                                          info.n_bdef1, info.n_bdef2, info.n_bdef4)
     if layout == api.OUT_VERTEX32:
         deform_bytes += ni * model.nv * 8 + model.nv * 8        # 32 B out + uv in
         step_bytes += ni * model.nv * 8 + model.nv * 8
-    achieved = deform_bytes / (skin_avg * 1e-3) / 1e9
+    achieved = deform_bytes / (kernel_ms * 1e-3) / 1e9
 
     result = {
         "metric": "skinned vertices/sec (instance-sharded crowd); achieved HBM GB/s vs roofline",
         "value": value, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "config3: 1024-instance crowd per GPU of the 50k-vert/300-bone/200-morph "
                                "model, shared morph state, per-instance palettes in HBM",
@@ -183,16 +235,26 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "deform_kernel (skinning + write-out)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": deform_bytes, "avg_kernel_ms": skin_avg,
-                     "uninstrumented_ms_per_step": plain_ms,
-                     "trailing_steps": args.steps,     # launches after the timed region (for trace post-processing)
-                     "step_algorithmic_bytes": step_bytes, "morph_pass_ms": morph_avg,
-                     "step_event_ms": ev_ms / args.steps, "output_placement": placement,
-                     "settle_batches_kernel_ms": [round(x, 4) for x in settle_batches]},
+                     "algorithmic_bytes_per_launch": deform_bytes, "avg_kernel_ms": kernel_ms,
+                     "avg_kernel_ms_how": f"{args.steps} back-to-back launches of the kernel alone between two HIP events "
+                                          "on its stream (rank 0)",
+                     # the whole step (morph pass + deform kernel) against the same peak, from the driver-checkable
+                     # ms_per_step: kernel and step figures must tell one story
+                     "step_algorithmic_bytes": step_bytes,
+                     "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "step_event_ms": ev_ms / args.steps,
+                     # per-kernel events on every launch (round 1's headline; flatters the kernel, see above)
+                     "event_bracketed_kernel_ms": skin_avg, "event_bracketed_morph_pass_ms": morph_avg,
+                     "event_bracketed_frac": deform_bytes / (skin_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     # deform-kernel launches after the timed region, oldest first (trace post-processing)
+                     "trace_segments": [["timed", args.steps], ["kernel_only", args.steps], ["event_bracketed", args.steps]],
+                     "output_placement": placement,
+                     "kernel_source_sha": kernel_source_sha(),
+                     "settle_batches_step_ms": [round(x, 4) for x in settle_batches]},
     }
 
     if rank == 0:
-        result["roofline"].update(pmc_traffic(layout == api.OUT_SOA))
+        result["roofline"].update(pmc_traffic(layout == api.OUT_SOA, ni, model.nv))
         result["device"] = device_name(local_rank % ndev)
         # practical ceilings on this box (SURVEY.md section 8d asks for them next to the spec peak)
         nb_ceiling = 1 << 30
@@ -210,7 +272,7 @@ def main():
             api.check(api.lib().mmdx_bench_store_pattern(d_a.ptr, d_b.ptr, model.nv, ni, 10, C.byref(ms)))
             result["roofline"]["measured_store_pattern_GBs"] = ni * model.nv * 24 / (ms.value * 1e-3) / 1e9
             step()      # leave real results in the output buffers
-            result["roofline"]["trailing_steps"] += 1
+            result["roofline"]["trace_segments"].append(["trailing", 1])
 
     # ---- CPU baseline: rank 0, N=1 only ------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -267,18 +329,38 @@ def main():
         print(json.dumps(result))
 
 
-def pmc_traffic(is_default_layout: bool):
+def kernel_source_sha() -> str:
+    """Identifies the revision of the code that shapes the deform launch (kernel, launch parameters, plan)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("kernels.hip", "kernels.hpp", "api.cpp", "plan.cpp", "plan.hpp"):
+        h.update(open(os.path.join(ROOT, "simple_mmd_renderer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(is_default_layout: bool, ni: int, nv: int):
     """HBM bytes per launch of the deform kernel from the committed rocprofv3 PMC passes
     (profiles/rNN/config3_pmc_hbm_traffic.csv: FETCH_SIZE and WRITE_SIZE collected in separate
     passes).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts wide streaming reads at
     half their bytes -- the same file's 1 GiB copy_kernel row (FETCH = 524 299 KB) confirms it -- so the
     read side is doubled; WRITE_SIZE is exact.  bench.py cannot drive PMC itself, hence a recorded
-    figure with its provenance, or null."""
+    figure with its provenance -- and only while that provenance matches this run: the summary's .meta.json
+    (tools/summarize_profiles.py) records the kernel source revision, instance and vertex counts it was
+    collected with; on any mismatch the figure is withheld (null) rather than going stale silently."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "config3_pmc_hbm_traffic.csv")))
     if not files or not is_default_layout:
         return {"traffic": None}
+    meta_path = files[-1][:-4] + ".meta.json"
+    src = os.path.relpath(files[-1], ROOT)
+    if not os.path.exists(meta_path):
+        return {"traffic": None, "traffic_withheld": f"{src}: no .meta.json (collected before the kernel revision was recorded)"}
+    meta = json.load(open(meta_path))
+    want = {"kernel_source_sha": kernel_source_sha(), "instances_per_gpu": ni, "vertices": nv}
+    diff = {k: (meta.get(k), v) for k, v in want.items() if meta.get(k) != v}
+    if diff or any(os.environ.get(k) for k in ("MMDX_GROUP", "MMDX_THREADS", "MMDX_INTERLEAVE", "MMDX_LDS_TARGET")):
+        return {"traffic": None, "traffic_withheld": f"{src} was collected for another build / workload: {diff}"}
     fetch = write = None
     for row in csv.DictReader(open(files[-1])):
         if "deform_kernel" in row["kernel"]:
@@ -289,8 +371,7 @@ def pmc_traffic(is_default_layout: bool):
     if fetch is None or write is None:
         return {"traffic": None}
     return {"traffic": write + 2 * fetch, "traffic_detail": {
-        "write_bytes": write, "fetch_bytes_reported": fetch, "fetch_correction": 2.0,
-        "source": os.path.relpath(files[-1], ROOT)}}
+        "write_bytes": write, "fetch_bytes_reported": fetch, "fetch_correction": 2.0, "source": src}}
 
 
 def time_calls(dm, fn, iters, warm=3, settle_ms=60.0):

@@ -120,8 +120,13 @@ enum {
     MMDX_PALETTE_ON_DEVICE = 1u << 0, /* palettes is a device pointer (else host, copied per call)  */
     MMDX_WEIGHTS_ON_DEVICE = 1u << 1, /* morph_weights is a device pointer                          */
     MMDX_OUT_ON_DEVICE = 1u << 2,     /* out_a/out_b are device pointers (else host; D2H + sync)   */
-    MMDX_WEIGHTS_SHARED = 1u << 3     /* one morph_weights[NM] for all instances (crowd with shared
+    MMDX_WEIGHTS_SHARED = 1u << 3,    /* one morph_weights[NM] for all instances (crowd with shared
                                          facial state): the morph pass runs once per call          */
+    MMDX_MORPH_UNCHANGED = 1u << 4    /* with MMDX_WEIGHTS_SHARED and NI > 1: the morph weights are those of the
+                                         previous such call on this model (a crowd whose facial state
+                                         changes less often than its poses): the morphed positions of that
+                                         call are reused and the morph pass is skipped; morph_weights is
+                                         not read.  An error without such an earlier call.            */
 };
 
 typedef struct mmdx_deform_args {
@@ -157,7 +162,11 @@ typedef struct mmdx_model_info {
 MMDX_API uint32_t mmdx_abi_version(void);
 MMDX_API const char *mmdx_last_error_string(void);
 MMDX_API mmdx_status mmdx_device_count(int32_t *count);
-MMDX_API mmdx_status mmdx_device_select(int32_t ordinal); /* device for subsequently created models */
+/* Device for the models, motions and buffers the CALLING THREAD creates from now on (like hipSetDevice), and the
+ * default for threads that never select one.  A handle stays on the device it was created on and may be used
+ * from any thread, one call at a time per handle; handles on different devices (or on the same one: each has its
+ * own stream) run concurrently from different host threads -- the in-process form of the instance-sharded crowd. */
+MMDX_API mmdx_status mmdx_device_select(int32_t ordinal);
 MMDX_API mmdx_status mmdx_device_name(int32_t ordinal, char *buf, size_t buf_size);
 
 /* ---- model ----------------------------------------------------------------------------------- */
@@ -220,6 +229,9 @@ MMDX_API mmdx_status mmdx_memcpy_h2d(void *dst_device, const void *src_host, siz
 MMDX_API mmdx_status mmdx_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
 MMDX_API mmdx_status mmdx_device_memset(void *dst_device, int value, size_t bytes);
 MMDX_API mmdx_status mmdx_device_synchronize(void);
+/* The launch-shape overrides for A/B runs (environment variables MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET,
+ * MMDX_INTERLEAVE; tools/ab.py) are read once per process; this re-reads them.  Not for product use. */
+MMDX_API void mmdx_debug_reload_env(void);
 /* Device-to-device streaming copy / fill timed with HIP events: the practical HBM ceiling printed
  * next to the roofline.  bytes_moved = 2*bytes for copy, bytes for fill. */
 MMDX_API mmdx_status mmdx_bench_copy(void *dst_device, const void *src_device, size_t bytes,

@@ -17,7 +17,7 @@ ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5:
 
 CREATE_NORMALIZE, CREATE_HOST_ONLY, CREATE_F16_POSITIONS = 1, 2, 4
 OUT_SOA, OUT_VERTEX32, OUT_SOA_POS16 = 0, 1, 2
-PALETTE_ON_DEVICE, WEIGHTS_ON_DEVICE, OUT_ON_DEVICE, WEIGHTS_SHARED = 1, 2, 4, 8
+PALETTE_ON_DEVICE, WEIGHTS_ON_DEVICE, OUT_ON_DEVICE, WEIGHTS_SHARED, MORPH_UNCHANGED = 1, 2, 4, 8, 16
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -89,6 +89,7 @@ SIGNATURES = {
     "mmdx_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mmdx_device_memset": (C.c_int32, [C.c_void_p, C.c_int, C.c_size_t]),
     "mmdx_device_synchronize": (C.c_int32, []),
+    "mmdx_debug_reload_env": (None, []),
     "mmdx_bench_copy": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
     "mmdx_bench_fill": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
     "mmdx_bench_store_pattern": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, _f32p]),

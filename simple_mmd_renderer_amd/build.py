@@ -30,8 +30,8 @@ def hipcc() -> str:
 
 
 def flags() -> list[str]:
-    extra = ["-DMMDX_ABLATE"] if os.environ.get("MMDX_BUILD_ABLATE") else []   # tools/ experiments only
-    if os.environ.get("MMDX_BUILD_DEFS"):
+    extra = []
+    if os.environ.get("MMDX_BUILD_DEFS"):      # tools/ experiments only
         extra += ["-D" + d for d in os.environ["MMDX_BUILD_DEFS"].split(",")]
     if os.environ.get("MMDX_BUILD_TILE"):
         extra.append("-DMMDX_TILE=" + os.environ["MMDX_BUILD_TILE"])

@@ -101,3 +101,49 @@ class Rendezvous:
             self._dist.barrier()
             self._dist.destroy_process_group()
             self._dist = None
+
+
+class InProcessCrowd:
+    """The in-process form of the sharded crowd: ONE process, one host thread + one model
+    handle (with its own HIP stream) per shard, shard s on device s % n_devices.  Every worker thread selects its
+    device (mmdx_device_select binds the calling thread, like hipSetDevice), creates its copy of the static
+    streams there and deforms its slice [s*NI/S, (s+1)*NI/S) of the instances; no data crosses shards.  ctypes
+    releases the GIL inside the library, so the shards' calls really run concurrently."""
+
+    def __init__(self, flat, n_shards: int, **model_kw):
+        import concurrent.futures as cf
+        from .engine import DeformModel, device_count, device_select
+        ndev = device_count()
+        if ndev < 1:
+            raise RuntimeError("InProcessCrowd: no HIP device visible (this engine has no CPU path)")
+        self.n_shards = int(n_shards)
+        self.devices = [s % ndev for s in range(self.n_shards)]
+        self._pools = [cf.ThreadPoolExecutor(1) for _ in range(self.n_shards)]   # one persistent thread per shard
+
+        def make(dev):
+            device_select(dev)
+            return DeformModel(flat, **model_kw)
+        self.models = [f.result() for f in [p.submit(make, d) for p, d in zip(self._pools, self.devices)]]
+
+    def deform(self, weights, palettes, shared_weights: bool = True, **kw):
+        """Host arrays in, host arrays out; instance i is handled by the shard whose range holds i."""
+        ni = palettes.shape[0]
+        parts = [shard_instances(ni, self.n_shards, s) for s in range(self.n_shards)]
+
+        def run(s):
+            lo, hi = parts[s]
+            if hi == lo:
+                return None
+            w = weights if shared_weights else weights[lo:hi]
+            return self.models[s].deform_batched(w, palettes[lo:hi], shared_weights=shared_weights, **kw)
+        outs = [f.result() for f in [self._pools[s].submit(run, s) for s in range(self.n_shards)]]
+        outs = [o for o in outs if o is not None]
+        if isinstance(outs[0], tuple):
+            return tuple(np.concatenate([o[k] for o in outs]) for k in range(len(outs[0])))
+        return np.concatenate(outs)
+
+    def close(self) -> None:
+        for p, m in zip(self._pools, self.models):
+            p.submit(m.close).result()
+            p.shutdown()
+        self.models, self._pools = [], []

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -25,7 +26,12 @@ using namespace mmdx;
 
 namespace {
 
-int g_device = 0;
+// Device selection follows hipSetDevice's model: mmdx_device_select() binds the CALLING THREAD (one host thread per
+// device may each select its own and create / run its models concurrently) and also becomes the default of
+// threads that never selected one (a process that selects once in its main thread and works from a pool).
+std::atomic<int> g_default_device{0};
+thread_local int tl_device = -1;
+int current_device() { return tl_device >= 0 ? tl_device : g_default_device.load(std::memory_order_relaxed); }
 std::once_flag g_prepare_once[16];
 hipError_t g_prepare_status[16];
 
@@ -90,6 +96,7 @@ struct mmdx_model_s {
         ell, entries, slot_top, chain_off, chain_rate;
     // per-call scratch (grown on demand, reused)
     DevBuf pal, rates, wslot, morphed, out_a, out_b;
+    bool morphed_valid = false;     // `morphed` holds the result of a shared morph pass (MMDX_MORPH_UNCHANGED)
     // page-locked bounce buffer for small outputs bound for pageable host memory (see mmdx_deform_batched)
     void *bounce = nullptr, *bounce_dev = nullptr;  // host address, device-side address
     size_t bounce_bytes = 0;
@@ -161,6 +168,20 @@ int env_int(const char *name, int dflt) {
     return s && *s ? std::atoi(s) : dflt;
 }
 
+// Launch-shape overrides for A/B runs (tools/): read ONCE, at the first deform call of the process -- the
+// per-frame call has a budget of a few microseconds and getenv walks the whole environment.
+struct LaunchOverrides {
+    int interleave, threads, lds_target, group, placement_log, placement_park;
+};
+LaunchOverrides read_launch_overrides() {
+    return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
+            env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0)};
+}
+LaunchOverrides &launch_overrides() {
+    static LaunchOverrides o = read_launch_overrides();
+    return o;
+}
+
 mmdx_status upload_model(mmdx_model_s *m) {
     Plan &p = m->plan;
     uint64_t &t = m->device_bytes;
@@ -229,7 +250,7 @@ mmdx_status mmdx::resolve_stream(mmdx_model_t model, int *device, hipStream_t *s
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(MMDX_ERR_NO_DEVICE, "no HIP device available (motion and rig evaluation run on the GPU)");
     const bool on_model = model && model->device >= 0;
-    *device = on_model ? model->device : g_device;
+    *device = on_model ? model->device : current_device();
     *stream = on_model ? model->stream : nullptr;
     HIP_TRY(hipSetDevice(*device));
     return MMDX_OK;
@@ -275,7 +296,8 @@ mmdx_status mmdx_device_select(int32_t ordinal) {
     if (ordinal < 0 || ordinal >= n || ordinal >= 16)
         return fail(MMDX_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     HIP_TRY(hipSetDevice(ordinal));
-    g_device = ordinal;
+    tl_device = ordinal;
+    g_default_device.store(ordinal, std::memory_order_relaxed);
     return MMDX_OK;
 }
 
@@ -318,7 +340,7 @@ mmdx_status mmdx_model_create(const mmdx_model_desc *desc, mmdx_model_t *out_mod
                     "no HIP device available (this engine has no CPU fallback; use "
                     "MMDX_CREATE_HOST_ONLY to validate a model without a GPU)");
     }
-    m->device = g_device;
+    m->device = current_device();
     auto bail = [&](mmdx_status s) { free_model(m); return s; };
     if ((e = hipSetDevice(m->device)) != hipSuccess) return bail(hip_fail(e, "hipSetDevice"));
     std::call_once(g_prepare_once[m->device], [&] { g_prepare_status[m->device] = prepare_kernels(); });
@@ -422,9 +444,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = m->stream;
     hipEvent_t *pev = nullptr;  // {skin0, skin1, morph0, morph1} of this call when profiling
-    if (m->profile && m->prof_seen++ % m->profile_stride == 0) {
-        if (m->prof_calls >= kMaxProfiledCalls)
-            return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_profile: too many calls without mmdx_profile_collect");
+    // a full recording (kMaxProfiledCalls without mmdx_profile_collect) stops recording; it never fails the call
+    if (m->profile && m->prof_calls < kMaxProfiledCalls && m->prof_seen++ % m->profile_stride == 0) {
         while (m->prof_events.size() < 4 * (m->prof_calls + 1)) {
             hipEvent_t ev;
             HIP_TRY(hipEventCreate(&ev));
@@ -452,10 +473,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     dp.pos_scale = a->pos_scale;
     dp.pal_stride = p.max_tile_bones * 3;
     dp.finite_offsets = p.finite_offsets ? 1u : 0u;
-    dp.interleave = uint32_t(env_int("MMDX_INTERLEAVE", 1));
-#ifdef MMDX_ABLATE
-    dp.ablate = uint32_t(env_int("MMDX_ABLATE", 0));
-#endif
+    const LaunchOverrides &ov = launch_overrides();
+    dp.interleave = uint32_t(ov.interleave);
 
     // ---- palettes -------------------------------------------------------------------------------
     const size_t pal_bytes = size_t(ni) * p.nb * 64;
@@ -495,7 +514,11 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (pev) HIP_TRY(hipEventRecord(pev[2], st));
         dp.wslot = f.out;
         dp.morphed = static_cast<float *>(m->morphed.ptr);
-        if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
+        if (morph == kMorphShared && (a->flags & MMDX_MORPH_UNCHANGED)) {
+            if (!m->morphed_valid)
+                return fail(MMDX_ERR_INVALID_ARGUMENT, "MMDX_MORPH_UNCHANGED without an earlier MMDX_WEIGHTS_SHARED "
+                                                       "crowd call on this model");
+        } else if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
             HIP_TRY(launch_morph_apply(p.f16, dp, &f, st));      // flatten fused in: one launch
         } else if (morph == kMorphFused1) {
             dp.fused_rates = rates_dev;                           // flatten inside the deform kernel
@@ -506,6 +529,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
             if (morph == kMorphShared) HIP_TRY(launch_morph_apply(p.f16, dp, nullptr, st));
         }
         if (pev) HIP_TRY(hipEventRecord(pev[3], st));
+        if (morph == kMorphShared) m->morphed_valid = true;
     }
 
     // ---- outputs ---------------------------------------------------------------------------------
@@ -553,7 +577,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // ---- workgroup shape ------------------------------------------------------------------------------
     // 256 threads / two vertex slots per lane everywhere except the per-instance-morph path: there one slot
     // per lane (512 threads) leaves the registers to serve 8 instances per walk over a morph row.
-    int threads = env_int("MMDX_THREADS", morph == kMorphFused4 ? 512 : 256) == 512 ? 512 : 256;
+    int threads = (ov.threads ? ov.threads : (morph == kMorphFused4 ? 512 : 256)) == 512 ? 512 : 256;
     if (morph == kMorphFused4 && threads == 512) {   // tiles with hundreds of bones: 8 palettes do not fit, 4 may
         uint32_t so, wo;
         if (deform_lds_bytes(512, layout, morph, 8, p.max_tile_bones, p.ns, &so, &wo) > 160 * 1024) threads = 256;
@@ -562,7 +586,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     const uint32_t gmin = morph == kMorphFused4 ? (threads == 512 ? 8u : 4u) : 1u;
     uint32_t group = gmin;
     if (morph != kMorphFused1) {
-        const uint32_t target = uint32_t(env_int("MMDX_LDS_TARGET", (morph == kMorphFused4 ? 64 : 42) * 1024));
+        const uint32_t target = uint32_t(ov.lds_target ? ov.lds_target : (morph == kMorphFused4 ? 64 : 42) * 1024);
         uint32_t so, wo;
         const size_t fixed = deform_lds_bytes(threads, layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);
         const size_t per = size_t(p.max_tile_bones) * 48;
@@ -579,7 +603,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
             g = half;
         }
         group = std::max(g, gmin);
-        const int forced = env_int("MMDX_GROUP", 0);
+        const int forced = ov.group;
         if (forced > 0) group = std::max(uint32_t(forced) / gmin * gmin, gmin);
     }
     dp.group = group;
@@ -705,7 +729,7 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(MMDX_ERR_NO_DEVICE, "no HIP device available (morph tracks are evaluated on the GPU)");
-    const int device = model && model->device >= 0 ? model->device : g_device;
+    const int device = model && model->device >= 0 ? model->device : current_device();
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = model && model->device >= 0 ? model->stream : nullptr;
     if (d.device != device) {
@@ -761,14 +785,14 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
 
 mmdx_status mmdx_device_malloc(void **ptr, size_t bytes) {
     if (!ptr) return fail(MMDX_ERR_INVALID_ARGUMENT, "ptr is NULL");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(current_device()));
     HIP_TRY(hipMalloc(ptr, bytes ? bytes : 16));
     return MMDX_OK;
 }
 
 mmdx_status mmdx_host_malloc(void **ptr, size_t bytes) {
     if (!ptr) return fail(MMDX_ERR_INVALID_ARGUMENT, "ptr is NULL");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(current_device()));
     HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
     return MMDX_OK;
 }
@@ -794,9 +818,15 @@ mmdx_status mmdx_memcpy_d2h(void *dst, const void *src, size_t bytes) {
 }
 
 mmdx_status mmdx_device_memset(void *dst, int value, size_t bytes) {
+    // hipMemset of device memory is asynchronous to the host and runs on the null stream, which the models'
+    // non-blocking streams do not wait for: complete it here, so that whatever the caller launches next (on any
+    // stream) is ordered after it.
     HIP_TRY(hipMemset(dst, value, bytes));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return MMDX_OK;
 }
+
+void mmdx_debug_reload_env(void) { launch_overrides() = read_launch_overrides(); }
 
 mmdx_status mmdx_device_synchronize(void) {
     HIP_TRY(hipDeviceSynchronize());
@@ -921,11 +951,11 @@ mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_
         if (e == hipSuccess) e = time_store_pattern(c.a, c.b, nv, n_instances, bpva, bpvb, 5, &ms);
         if (e != hipSuccess) { release(c); st = hip_fail(e, "probing a placement of the crowd output arrays"); break; }
         c.gbs = float(double(bytes_a + bytes_b) / (ms * 1e-3) / 1e9);
-        if (env_int("MMDX_PLACEMENT_LOG", 0))
+        if (launch_overrides().placement_log)
             std::fprintf(stderr, "mmdx placement try %u: a=%p b=%p store %.0f GB/s (fill %.0f)\n", tries, c.a, c.b, c.gbs, fill_gbs);
         // measured (tools/shop_probe.py): about one placement in seven is fast either way; freeing a rejected
         // candidate at once needs a few tries less on average than keeping it parked, and no extra memory
-        const bool park = env_int("MMDX_PLACEMENT_PARK", 0) != 0;
+        const bool park = launch_overrides().placement_park != 0;
         if (c.gbs > best.gbs) {
             if (best.a) { if (park) parked.push_back(best); else release(best); }
             best = c;

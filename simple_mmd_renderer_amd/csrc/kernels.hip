@@ -114,14 +114,11 @@ __device__ __forceinline__ void xform_nrm(const M12 &m, v2f xy, float z, v2f &ox
 // LDS element (shift + i) <-> out[base + i], shift = base % (16/sizeof(T)).
 template <typename T>
 __device__ __forceinline__ void copy_chunk(const unsigned char *img, T *g, uint32_t q, uint32_t shift,
-                                           uint32_t n, bool aligned16, bool no_store) {
+                                           uint32_t n, bool aligned16) {
     constexpr uint32_t EPC = 16 / sizeof(T);
     const uint32_t lo = q * EPC;
     if (aligned16 && lo >= shift && lo + EPC <= shift + n) {
         const float4 v = *reinterpret_cast<const float4 *>(img + size_t(q) * 16);
-#ifdef MMDX_ABLATE
-        if (no_store) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
-#endif
         *reinterpret_cast<float4 *>(g + lo) = v;
     } else {
         const T *l = reinterpret_cast<const T *>(img);
@@ -138,14 +135,14 @@ template <int THREADS, typename TA, typename TB>
 __device__ __forceinline__ void copy_out2(const unsigned char *imgA, TA *outA, size_t baseA,
                                           uint32_t shA, uint32_t nA, const unsigned char *imgB,
                                           TB *outB, size_t baseB, uint32_t shB, uint32_t nB,
-                                          bool aligned16, int tid, bool no_store) {
+                                          bool aligned16, int tid) {
     const uint32_t ncA = (shA + nA + 16 / sizeof(TA) - 1) / (16 / sizeof(TA));
     const uint32_t ncB = (shB + nB + 16 / sizeof(TB) - 1) / (16 / sizeof(TB));
     TA *gA = outA + baseA - shA;
     TB *gB = outB + baseB - shB;
     for (uint32_t q = tid; q < ncA + ncB; q += THREADS) {
-        if (q < ncA) copy_chunk<TA>(imgA, gA, q, shA, nA, aligned16, no_store);
-        else copy_chunk<TB>(imgB, gB, q - ncA, shB, nB, aligned16, no_store);
+        if (q < ncA) copy_chunk<TA>(imgA, gA, q, shA, nA, aligned16);
+        else copy_chunk<TB>(imgB, gB, q - ncA, shB, nB, aligned16);
     }
 }
 
@@ -160,7 +157,7 @@ struct CopyFast {
     // issued before the first store), then store it.  Scalars only -- an indexed float4 array here
     // ends up in scratch memory with a vmcnt(0) in front of every store.
     static __device__ __forceinline__ void run(const unsigned char *img, uint32_t gapB, float4 *outA,
-                                               float4 *outB, int tid, bool no_store) {
+                                               float4 *outB, int tid) {
         constexpr int TOTAL = CA + CB;
         if constexpr (I * THREADS < TOTAL) {
             constexpr bool full = (I + 1) * THREADS <= TOTAL;
@@ -170,10 +167,7 @@ struct CopyFast {
             if (full || q < TOTAL)
                 v = *reinterpret_cast<const float4 *>(img + (inA ? 0u : gapB - uint32_t(CA) * 16u) +
                                                       size_t(q) * 16);
-            CopyFast<THREADS, CA, CB, I + 1>::run(img, gapB, outA, outB, tid, no_store);
-#ifdef MMDX_ABLATE
-            if (no_store) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
-#endif
+            CopyFast<THREADS, CA, CB, I + 1>::run(img, gapB, outA, outB, tid);
             if (full || q < TOTAL) {
                 float4 *dst = inA ? outA + q : outB + (q - CA);
                 *dst = v;
@@ -183,8 +177,8 @@ struct CopyFast {
 };
 template <int THREADS, int CA, int CB>
 __device__ __forceinline__ void copy_out_fast(const unsigned char *img, uint32_t gapB, float4 *outA,
-                                              float4 *outB, int tid, bool no_store) {
-    CopyFast<THREADS, CA, CB, 0>::run(img, gapB, outA, outB, tid, no_store);
+                                              float4 *outB, int tid) {
+    CopyFast<THREADS, CA, CB, 0>::run(img, gapB, outA, outB, tid);
 }
 
 struct Slot {
@@ -299,9 +293,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     constexpr uint32_t kStage = stage_bytes(LAYOUT);
 
     // 1. bone palettes of the group's instances -> LDS: only the tile's bones, in the pair layout
-#ifdef MMDX_ABLATE
-    if (!(p.ablate & 32u))
-#endif
     for (uint32_t idx = tid; idx < gcount * nbt; idx += THREADS) {
         const uint32_t g = idx / nbt, lb = idx - g * nbt;
         const uint32_t bone = p.bone_list[th.bone_off + lb];
@@ -338,9 +329,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         q.w0 = q.w1 = q.w2 = q.w3 = 0.f;
         q.b0 = q.b1 = q.b2 = q.b3 = 0;
         q.perm = 0; q.rb = q.rlen = 0;
-#ifdef MMDX_ABLATE
-        if (p.ablate & 64u) { q.perm = s; continue; }
-#endif
         if (q.act) {
             const size_t gs = size_t(v0) + s;
             if constexpr (MORPH == kMorphShared) {
@@ -395,13 +383,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             const Slot &q = sl[k];
             if (!q.act) continue;
             M12 m;
-#ifdef MMDX_ABLATE
-            if (p.ablate & 16u) continue;   // stores only: no palette reads, math or image writes
-            if (p.ablate & 2u) {
-                m.p0 = v2f{1.f, 0.f}; m.p1 = v2f{0.f, 1.f}; m.p2 = v2f{0.f, 0.f}; m.p3 = v2f{0.f, 0.f};
-                m.q0 = v2f{0.f, 0.f}; m.q1 = v2f{1.f, 0.f};
-            } else
-#endif
             if (q.cls == 0) {
                 m = load_m12(P, q.b0);
             } else if (q.cls == 1) {
@@ -427,12 +408,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             // pos_scale is a separate multiply after the transform (main.cpp:848-850); x*1.0f == x
             oxy = oxy * p.pos_scale;
             oz = oz * p.pos_scale;
-#ifdef MMDX_ABLATE
-            if (p.ablate & 4u) {
-                asm volatile("" ::"v"(oxy.x), "v"(oxy.y), "v"(oz), "v"(rxy.x), "v"(rxy.y), "v"(rz));
-                continue;
-            }
-#endif
             if constexpr (LAYOUT == MMDX_OUT_SOA) {
                 float *A = reinterpret_cast<float *>(img) + sh4 + q.perm * 3;
                 float *B = reinterpret_cast<float *>(img + kSoaImgBytes) + sh4 + q.perm * 3;
@@ -449,15 +424,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                 B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
             }
         }
-#ifdef MMDX_ABLATE
-        if (p.ablate & 4u) return;
-        const bool ns = (p.ablate & 1u) != 0;
-#else
-        constexpr bool ns = false;
-#endif
-#ifdef MMDX_ABLATE
-        if (!(p.ablate & 8u))
-#endif
         __syncthreads();
         const bool fast = al && nvt == kTileVerts && sh4 == 0 && sh8 == 0;
         if constexpr (LAYOUT == MMDX_OUT_SOA) {
@@ -465,29 +431,29 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             if (fast)
                 copy_out_fast<THREADS, kTileVerts * 12 / 16, kTileVerts * 12 / 16>(
                     img, kSoaImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
-                    reinterpret_cast<float4 *>(ob + vbase * 3), tid, ns);
+                    reinterpret_cast<float4 *>(ob + vbase * 3), tid);
             else
                 copy_out2<THREADS, float, float>(img, oa, vbase * 3, sh4, nvt * 3, img + kSoaImgBytes, ob,
-                                                 vbase * 3, sh4, nvt * 3, al, tid, ns);
+                                                 vbase * 3, sh4, nvt * 3, al, tid);
         } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
             float *oa = reinterpret_cast<float *>(p.out_a);
             if (fast)
                 copy_out_fast<THREADS, kTileVerts * 32 / 16, 0>(
-                    img, 0u, reinterpret_cast<float4 *>(oa + vbase * 8), nullptr, tid, ns);
+                    img, 0u, reinterpret_cast<float4 *>(oa + vbase * 8), nullptr, tid);
             else
                 copy_out2<THREADS, float, float>(img, oa, vbase * 8, 0u, nvt * 8, img, oa, 0, 0u, 0u, al,
-                                                 tid, ns);
+                                                 tid);
         } else {
             unsigned short *oa = reinterpret_cast<unsigned short *>(p.out_a);
             float *ob = reinterpret_cast<float *>(p.out_b);
             if (fast)
                 copy_out_fast<THREADS, kTileVerts * 6 / 16, kTileVerts * 12 / 16>(
                     img, kP16ImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
-                    reinterpret_cast<float4 *>(ob + vbase * 3), tid, ns);
+                    reinterpret_cast<float4 *>(ob + vbase * 3), tid);
             else
                 copy_out2<THREADS, unsigned short, float>(img, oa, vbase * 3, sh8, nvt * 3,
                                                           img + kP16ImgBytes, ob, vbase * 3, sh4, nvt * 3,
-                                                          al, tid, ns);
+                                                          al, tid);
         }
         buf ^= 1u;  // double-buffered image: the next instance writes the other one, so one barrier
                     // per instance is enough
@@ -551,16 +517,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                         w[4] = b4.x; w[5] = b4.y; w[6] = b4.z; w[7] = b4.w;
                     }
                 };
-#ifdef MMDX_ABLATE
-                if (p.ablate & 128u) {           // no morph gather at all
-                } else if (p.ablate & 256u) {    // gather without the LDS weight lookups
-                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
-                        const float w = __uint_as_float(slot | 0x3f000000u);
-#pragma unroll
-                        for (int j = 0; j < kPack; ++j) { dxy[k][j] += oxy * w; dz[k][j] += oz * w; }
-                    });
-                } else
-#endif
                 if (p.finite_offsets) {
                     // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves

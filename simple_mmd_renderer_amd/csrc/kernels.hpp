@@ -59,8 +59,6 @@ struct DeformParams {
     uint32_t out_aligned;        // out_a and out_b are 16-byte aligned
     uint32_t finite_offsets;     // every vertex-morph offset is finite (branch-free morph skip is exact)
     uint32_t interleave;         // crowd modes: instance = g*ngroups + grp instead of grp*group + g
-    uint32_t ablate;             // MMDX_ABLATE builds only (tools/): bit0 no global stores,
-                                 // bit1 no skinning math, bit2 no staging/copy-out at all
 };
 
 struct FlattenParams {

@@ -60,3 +60,29 @@ def test_sharded_crowd_equals_single_process(oracle, tmp_path, world):
         pos, nrm = oracle.skin(model, pals[i], vimg, skin)
         want.append(synth.checksum64(np.concatenate([pos.ravel(), nrm.ravel()])))
     assert res["checksums"] == want
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks_dry(world):
+    """`python bench.py --gpus N` with no launcher and no WORLD_SIZE: the parent starts N fresh rank processes
+    (before anything could touch a GPU), they rendezvous over gloo, and ONE JSON line comes back.  --dry-run stops
+    before the GPU work, which is what this container can run; the GPU box runs the same launcher for real
+    (tests/test_multi_device.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run",
+                        "--steps", "3", "--warmup", "1", "--instances-per-gpu", "10"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    import json as _json
+    line = _json.loads(lines[0])
+    assert line["n_gpus"] == world and line["instances"] == 10 * world
+    assert line["ranges"] == [[10 * k, 10 * (k + 1)] for k in range(world)]
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "x"],
+                       env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0

@@ -487,6 +487,130 @@ def test_config3_crowd_full_size_properties(oracle):
             b.free()
 
 
+def _device_io(dm, m, rates, pals, layout, shared=False):
+    """Run one batched call the way bench.py does (everything resident in HBM) and hand back the output buffers."""
+    ni = pals.shape[0]
+    d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
+    sa, sb = dm.out_sizes(layout, ni)
+    d_a, d_b = DeviceBuffer(sa), DeviceBuffer(max(sb, 16))
+    d_a.memset(0xFF); d_b.memset(0xFF)
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | (api.WEIGHTS_SHARED if shared else 0)
+    dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if sb else None, layout, flags)
+    dm.sync()
+    d_pal.free(); d_w.free()
+    return d_a, d_b
+
+
+def test_config2_full_size_single_frames(oracle):
+    """BASELINE config 2 at its size (50 000 verts / 300 bones / 200 active morphs, f32): ONE frame per call
+    through mmdx_deform (morph gather + group flatten fused into the deform kernel, kMorphFused1), as the viewer's
+    frame() would call it -- every vertex of several frames against the oracle, SoA and 32-byte layouts."""
+    m = synth.make_config("config2_50k")
+    frames = [0, 1, 17, 63, 599]
+    rates = synth.morph_weights(m.nm, frames)
+    pals = synth.make_palettes(m, frames)
+    assert (rates > 1e-7).sum(axis=1).min() >= 150              # "200 active morphs": most of them really are
+    with DeformModel(m) as dm:
+        for k, f in enumerate(frames):
+            pos, nrm = dm.deform(rates[k], pals[k])
+            ep, en = oracle_expect(oracle, m, rates[k], pals[k])
+            gu.assert_bits_equal(pos, ep, f"config2 frame {f} pos")
+            gu.assert_bits_equal(nrm, en, f"config2 frame {f} nrm")
+            v32 = dm.deform_vertex32(rates[k], pals[k], 0.1)
+            gu.assert_bits_equal(v32, oracle.repack32(m, ep, en, 0.1), f"config2 frame {f} v32")
+
+
+def test_config2_full_size_64_frames_per_launch(oracle):
+    """BASELINE config 2, the bandwidth form bench.py times: 64 frames of the 50k model in ONE launch with
+    per-frame morph weights (kMorphFused4: 512-thread workgroups, 8 instances per walk over a morph row), all
+    buffers in HBM -- EVERY frame, every vertex against the oracle."""
+    m = synth.make_config("config2_50k")
+    nfr = 64
+    frames = np.arange(nfr)
+    rates = synth.morph_weights(m.nm, frames)
+    pals = synth.make_palettes(m, frames)
+    with DeformModel(m) as dm:
+        d_a, d_b = _device_io(dm, m, rates, pals, api.OUT_SOA)
+        pos = d_a.download((nfr, m.nv, 3), np.float32)
+        nrm = d_b.download((nfr, m.nv, 3), np.float32)
+        d_a.free(); d_b.free()
+        skin = oracle.normalize(m)
+        for i in range(nfr):
+            ep, en = oracle.skin(m, pals[i], oracle.morph(m, rates[i]), skin)
+            gu.assert_bits_equal(pos[i], ep, f"config2 x64 frame {i} pos")
+            gu.assert_bits_equal(nrm[i], en, f"config2 x64 frame {i} nrm")
+        # a ragged count (not a multiple of the 8-instance walk) through the host-pointer form of the same call
+        p2, n2 = dm.deform_batched(rates[:13], pals[:13])
+        assert np.array_equal(p2.view(np.uint32), pos[:13].view(np.uint32))
+        assert np.array_equal(n2.view(np.uint32), nrm[:13].view(np.uint32))
+
+
+def test_config3_crowd_every_instance_vs_oracle(oracle):
+    """BASELINE config 3 exactly as bench.py runs it (1024 instances, shared morph state, crowd_frames palettes,
+    outputs in HBM): ALL 1024 instances, every vertex, bit for bit against the oracle."""
+    from simple_mmd_renderer_amd.crowd import crowd_frames
+    m = synth.make_config("config3_crowd")
+    ni = 1024
+    pals = synth.make_palettes(m, crowd_frames(0, ni))
+    rates = synth.morph_weights(m.nm, 30)[0]
+    with DeformModel(m) as dm:
+        d_a, d_b = _device_io(dm, m, rates, pals, api.OUT_SOA, shared=True)
+        skin = oracle.normalize(m)
+        vimg = oracle.morph(m, rates)
+        row = m.nv * 12
+        chunk = 128
+        for c in range(0, ni, chunk):
+            pos = d_a.download((chunk, m.nv, 3), np.float32, offset=c * row)
+            nrm = d_b.download((chunk, m.nv, 3), np.float32, offset=c * row)
+            for j in range(chunk):
+                ep, en = oracle.skin(m, pals[c + j], vimg, skin)
+                gu.assert_bits_equal(pos[j], ep, f"crowd inst {c + j} pos")
+                gu.assert_bits_equal(nrm[j], en, f"crowd inst {c + j} nrm")
+        d_a.free(); d_b.free()
+
+
+def test_config3prime_per_instance_morph_crowd_sample(oracle):
+    """Config 3' (every instance its own facial state, 1024 x 50k, fused gather): a strided sample of 64 instances
+    plus the first and last packs of 8, every vertex against the oracle."""
+    m = synth.make_config("config3_crowd")
+    ni = 1024
+    fr = (np.arange(ni) * 7) % 600
+    rates = synth.morph_weights(m.nm, fr)
+    pals = synth.make_palettes(m, fr)
+    with DeformModel(m) as dm:
+        d_a, d_b = _device_io(dm, m, rates, pals, api.OUT_SOA)
+        skin = oracle.normalize(m)
+        row = m.nv * 12
+        sample = sorted(set(range(0, ni, 16)) | set(range(8)) | set(range(ni - 8, ni)))
+        for i in sample:
+            ep, en = oracle.skin(m, pals[i], oracle.morph(m, rates[i]), skin)
+            gu.assert_bits_equal(d_a.download((m.nv, 3), np.float32, offset=i * row), ep, f"3' inst {i} pos")
+            gu.assert_bits_equal(d_b.download((m.nv, 3), np.float32, offset=i * row), en, f"3' inst {i} nrm")
+        d_a.free(); d_b.free()
+
+
+def test_config5_fp16_64_frames_per_launch(oracle):
+    """BASELINE config 5 in the form bench.py times (64 frames per launch, f16 positions, per-frame morph weights):
+    every 4th frame plus the last pack, every vertex against the f32 oracle on f16-quantised inputs."""
+    m = synth.make_config("config5_256k")
+    q = m.copy()
+    q.positions = m.positions.astype(np.float16).astype(np.float32)
+    q.morph_value = m.morph_value.astype(np.float16).astype(np.float32)
+    nfr = 64
+    frames = np.arange(nfr)
+    rates = synth.morph_weights(m.nm, frames)
+    pals = synth.make_palettes(m, frames)
+    with DeformModel(m, f16_positions=True) as dm:
+        d_a, d_b = _device_io(dm, m, rates, pals, api.OUT_SOA_POS16)
+        skin = oracle.normalize(q)
+        for i in sorted(set(range(0, nfr, 4)) | set(range(nfr - 8, nfr))):
+            ep, en = oracle.skin(q, pals[i], oracle.morph(q, rates[i]), skin)
+            got16 = d_a.download((m.nv, 3), np.float16, offset=i * m.nv * 6)
+            assert np.array_equal(got16.view(np.uint16), ep.astype(np.float16).view(np.uint16)), f"config5 frame {i} pos16"
+            gu.assert_bits_equal(d_b.download((m.nv, 3), np.float32, offset=i * m.nv * 12), en, f"config5 frame {i} nrm")
+        d_a.free(); d_b.free()
+
+
 def test_config5_fp16_full_size_sample(oracle):
     """262 144 verts / 512 bones / 1024 morphs x 4096 entries, f16 positions: one frame against the
     oracle (f16-quantised inputs), plus idempotence of a repeated call."""

@@ -5,7 +5,7 @@ N configurations x R rounds, median and min of the HIP-event kernel time per con
     python tools/ab.py "MMDX_GROUP=16" "MMDX_GROUP=8 MMDX_THREADS=256" ...
 
 Each argument is a space-separated list of VAR=VALUE settings read by libmmdx at call time
-(MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET, and MMDX_ABLATE in ablation builds).
+(MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET, MMDX_INTERLEAVE; re-read through mmdx_debug_reload_env).
 Workload: BASELINE config 3 (1024 x 50k crowd, shared morphs), override with AB_WORKLOAD=v32.
 AB_DENSE=1: no events, wall clock per whole step (morph pass + deform kernel back to back) instead of the
 event-bracketed deform kernel.
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
 
-KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_ABLATE", "MMDX_INTERLEAVE")
+KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_INTERLEAVE")
 
 
 def main():
@@ -47,6 +47,7 @@ def main():
             for k in KNOBS:
                 os.environ.pop(k, None)
             os.environ.update(cfg)
+            api.lib().mmdx_debug_reload_env()
             def burst(n_):
                 for _ in range(n_):                 # back-to-back, no host sync: sustained rate
                     dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout,

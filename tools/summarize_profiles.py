@@ -6,10 +6,12 @@ committed under profiles/<round>/:  python tools/summarize_profiles.py gpurun_ou
   all_workloads_kernel_stats.csv  the same with bench.py's secondary workloads on: every kernel of the library
   config3_bench.json              the plain bench line of the same box
   config3_bench_under_rocprof.json the line printed while tracing (HIP-event time to compare with the trace)
-  config3_kernel_trace_timed_region.csv  per-kernel average over the `steps` dispatches of bench.py's timed region
-                                  and over the uninstrumented repeat that follows it (the stats file above
-                                  also averages the untimed settle / warm-up launches, which run through the
-                                  clock transient)
+  config3_kernel_trace_timed_region.csv  deform-kernel average per segment of bench.py's run (timed region, the
+                                  kernel-only launches behind roofline.frac, the event-bracketed repeat; the
+                                  stats file above also averages the untimed settle / warm-up launches, which
+                                  run through the clock transient)
+  config3_pmc_hbm_traffic.meta.json  build + workload the PMC passes were collected for (bench.py withholds
+                                  roofline.traffic when they do not match its own run)
 """
 import collections
 import csv
@@ -27,20 +29,28 @@ def main(src, dst):
         shutil.copy(os.path.join(src, "kt_all", "all_kernel_stats.csv"), os.path.join(dst, "all_workloads_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "config3_bench_under_rocprof.json"))
     line = json.load(open(os.path.join(src, "bench_under_rocprof.json")))
-    steps, trailing = line["steps"], line["roofline"].get("trailing_steps", 0)
+    segs = line["roofline"]["trace_segments"]          # deform-kernel launches at the end of the run, oldest first
     per = collections.OrderedDict()
     with open(os.path.join(src, "kt", "kt_kernel_trace.csv"), newline="") as f:
         for r in csv.DictReader(f):
             per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(os.path.join(dst, "config3_kernel_trace_timed_region.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "dispatches_in_trace", "timed_n", "avg_ns_timed_region", "min_ns_timed_region",
-                    "max_ns_timed_region", "avg_ns_uninstrumented_repeat", "avg_ns_all"])
+        w.writerow(["kernel", "dispatches_in_trace", "segment", "n", "avg_ns", "min_ns", "max_ns", "avg_ns_all"])
         for k, v in per.items():
-            if "deform_kernel" in k or "morph_apply" in k:
-                t = v[len(v) - trailing - steps:len(v) - trailing]       # the K launches bracketed by events
-                u = v[len(v) - trailing:len(v) - trailing + steps]      # the same K steps repeated without events
-                w.writerow([k, len(v), len(t), sum(t) / len(t), min(t), max(t), sum(u) / len(u) if u else "", sum(v) / len(v)])
+            if "deform_kernel" in k:
+                pos = len(v) - sum(n for _, n in segs)
+                for name, n in segs:
+                    t = v[pos:pos + n]
+                    pos += n
+                    w.writerow([k, len(v), name, len(t), sum(t) / len(t), min(t), max(t), sum(v) / len(v)])
+            elif "morph_apply" in k:
+                w.writerow([k, len(v), "all", len(v), sum(v) / len(v), min(v), max(v), sum(v) / len(v)])
+    # provenance of the PMC figures bench.py quotes as roofline.traffic: the build and workload they were collected for
+    with open(os.path.join(dst, "config3_pmc_hbm_traffic.meta.json"), "w") as f:
+        json.dump({"kernel_source_sha": line["roofline"]["kernel_source_sha"],
+                   "instances_per_gpu": line["config"]["instances_per_gpu"], "vertices": line["config"]["vertices"],
+                   "collected_with": "tools/profile_round.sh (separate --pmc passes)"}, f, indent=1)
     rows = []
     for counter, path in (("FETCH_SIZE", "pmc_fetch/fetch_counter_collection.csv"),
                           ("WRITE_SIZE", "pmc_write/write_counter_collection.csv")):
