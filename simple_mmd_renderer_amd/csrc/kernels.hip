@@ -95,6 +95,21 @@ __device__ __forceinline__ M12 blend4(const M12 &a, const M12 &b, const M12 &c, 
     r.q1 = blend4_pair(a.q1, b.q1, c.q1, d.q1, w0, w1, w2, w3);
     return r;
 }
+// the same blend in steps: a*wa + b*wb, then t + c*wc
+__device__ __forceinline__ M12 mul_add(const M12 &a, float wa, const M12 &b, float wb) {
+    M12 r;
+    r.p0 = a.p0 * wa + b.p0 * wb; r.p1 = a.p1 * wa + b.p1 * wb;
+    r.p2 = a.p2 * wa + b.p2 * wb; r.p3 = a.p3 * wa + b.p3 * wb;
+    r.q0 = a.q0 * wa + b.q0 * wb; r.q1 = a.q1 * wa + b.q1 * wb;
+    return r;
+}
+__device__ __forceinline__ M12 add_mul(const M12 &t, const M12 &c, float wc) {
+    M12 r;
+    r.p0 = t.p0 + c.p0 * wc; r.p1 = t.p1 + c.p1 * wc;
+    r.p2 = t.p2 + c.p2 * wc; r.p3 = t.p3 + c.p3 * wc;
+    r.q0 = t.q0 + c.q0 * wc; r.q1 = t.q1 + c.q1 * wc;
+    return r;
+}
 // transform(): out[j] = ((x*m0j + y*m1j) + z*m2j) + m3j   (math_impl.inl:1039-1045)
 __device__ __forceinline__ void xform_pos(const M12 &m, v2f xy, float z, v2f &oxy, float &oz) {
     oxy = ((m.p0 * xy.x + m.p1 * xy.y) + m.p2 * z) + m.p3;
@@ -202,31 +217,58 @@ struct RawEntry { using type = float4; };
 template <>
 struct RawEntry<true> { using type = uint2; };
 
-template <bool F16, typename Body>
-__device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint32_t len, Body body) {
+constexpr uint32_t kRowAhead = 4;   // entries in flight per lane; deeper (8) costs the fused kernels a wave per SIMD and loses: measured
+
+template <bool F16>
+struct RowHead {                    // the first kRowAhead entries of a row, loaded ahead of their use
+    typename RawEntry<F16>::type e[kRowAhead];
+};
+// Entry j of a row sits at byte (base + j*64) * sizeof(entry) of the table: a wave-uniform 64-bit base plus a 32-bit
+// per-lane offset (plan.cpp keeps the table under 4 GiB), so a lane carries one address register, not a pointer pair.
+template <bool F16>
+__device__ __forceinline__ typename RawEntry<F16>::type row_entry(const void *entries, uint32_t base, uint32_t j) {
     using Raw = typename RawEntry<F16>::type;
-    const Raw *ent = reinterpret_cast<const Raw *>(entries) + base;
+    const uint32_t off = (base + j * 64u) * uint32_t(sizeof(Raw));
+    return *reinterpret_cast<const Raw *>(static_cast<const unsigned char *>(entries) + off);
+}
+template <bool F16>
+__device__ __forceinline__ void row_prefetch(const void *entries, uint32_t base, uint32_t len, RowHead<F16> &h) {
+    using Raw = typename RawEntry<F16>::type;
+    const uint32_t last = len ? len - 1 : 0u;
+    // every element is (re)defined on every path, so that a head requested for the next pack is not kept alive
+    // across the code in front of the request
+#pragma unroll
+    for (uint32_t i = 0; i < kRowAhead; ++i) {
+        Raw v = Raw{};
+        if (len) v = row_entry<F16>(entries, base, min(i, last));
+        h.e[i] = v;
+    }
+}
+template <bool F16, typename Body>
+__device__ __forceinline__ void row_consume(const void *entries, uint32_t base, uint32_t len, const RowHead<F16> &h,
+                                            Body body) {
+    using Raw = typename RawEntry<F16>::type;
     auto apply = [&](const Raw r) {
         if constexpr (F16) {
-            body(v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)}, h2f(r.y & 0xffffu), uint32_t(r.y >> 16));
+            body(h2f(r.x & 0xffffu), h2f(r.x >> 16), h2f(r.y & 0xffffu), uint32_t(r.y >> 16));
         } else {
-            body(v2f{r.x, r.y}, r.z, __float_as_uint(r.w));
+            body(r.x, r.y, r.z, __float_as_uint(r.w));
         }
     };
     // software-pipelined: the next B entries are in flight while the current B are consumed (the
     // gather is a chain of L2 round trips; with ~3 resident waves per SIMD nothing else hides them)
-    constexpr uint32_t B = 4;   // deeper (8) costs the fused kernels a wave per SIMD and loses: measured
+    constexpr uint32_t B = kRowAhead;
     if (len == 0) return;
     const uint32_t last = len - 1;
     Raw cur[B], nxt[B];
 #pragma unroll
-    for (uint32_t i = 0; i < B; ++i) cur[i] = ent[size_t(min(i, last)) * 64];
+    for (uint32_t i = 0; i < B; ++i) cur[i] = h.e[i];
     for (uint32_t j = 0; j < len; j += B) {
 #pragma unroll
         for (uint32_t i = 0; i < B; ++i) nxt[i] = cur[i];
         if (j + B < len) {
 #pragma unroll
-            for (uint32_t i = 0; i < B; ++i) nxt[i] = ent[size_t(min(j + B + i, last)) * 64];
+            for (uint32_t i = 0; i < B; ++i) nxt[i] = row_entry<F16>(entries, base, min(j + B + i, last));
         }
 #pragma unroll
         for (uint32_t i = 0; i < B; ++i)
@@ -234,6 +276,12 @@ __device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint
 #pragma unroll
         for (uint32_t i = 0; i < B; ++i) cur[i] = nxt[i];
     }
+}
+template <bool F16, typename Body>
+__device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint32_t len, Body body) {
+    RowHead<F16> h;
+    row_prefetch<F16>(entries, base, len, h);
+    row_consume<F16>(entries, base, len, h, body);
 }
 
 // Group-morph recursion of one slot (UpdateMorphTransform, poser_impl.inl:328-339): rate[top] times the
@@ -250,6 +298,213 @@ __device__ __forceinline__ float slot_weight(const float *rates, const uint32_t 
     return skip ? 0.f : r;
 }
 
+// ---- pieces shared by the deform kernels ------------------------------------------------------------
+// XCD-aware work mapping (speed only, never correctness): workgroup ids are dealt round-robin over
+// the 8 XCDs, each with a private 4 MiB L2.  XCD x gets a CONTIGUOUS range of tiles for all
+// instance groups, tile index fastest, so the ~96 workgroups resident on one XCD are (its ~12 tiles)
+// x (8 groups): a tile's static streams and the palette rows neighbouring tiles share are fetched
+// into that L2 once instead of once per XCD.  Tiles left over by ntiles % 8 are split by groups.
+// Returns false for a padding workgroup.
+__device__ __forceinline__ bool map_workgroup(const DeformParams &p, uint32_t &tile, uint32_t &grp) {
+    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const uint32_t T = p.ntiles >> 3, main_count = T * p.ngroups;
+    if (k < main_count) {
+        grp = k / T;
+        tile = xcd * T + (k - grp * T);
+        return true;
+    }
+    const uint32_t r = xcd * p.rem_per_xcd + (k - main_count);
+    if (r >= (p.ntiles & 7u) * p.ngroups) return false;
+    const uint32_t rt = r / p.ngroups;
+    tile = 8u * T + rt;
+    grp = r - rt * p.ngroups;
+    return true;
+}
+
+// static per-vertex data of sorted slot s of tile `th` -> registers
+template <int LAYOUT, int MORPH, bool F16>
+__device__ __forceinline__ void load_slot(const DeformParams &p, const TileHdr &th, uint32_t s, Slot &q) {
+    const uint32_t n1 = th.n1, n12 = th.n1 + th.n2;
+    q.act = s < th.nv;
+    q.cls = s < n1 ? 0 : (s < n12 ? 1 : 2);
+    q.pxy = q.nxy = q.uv = v2f{0.f, 0.f};
+    q.pz = q.nz = 0.f;
+    q.w0 = q.w1 = q.w2 = q.w3 = 0.f;
+    q.b0 = q.b1 = q.b2 = q.b3 = 0;
+    q.perm = 0; q.rb = q.rlen = 0;
+    if (!q.act) return;
+    const size_t gs = size_t(th.v0) + s;
+    if constexpr (MORPH == kMorphShared) {
+        q.pxy = v2f{p.morphed[gs * 3], p.morphed[gs * 3 + 1]}; q.pz = p.morphed[gs * 3 + 2];
+    } else if constexpr (F16) {
+        const uint2 r = reinterpret_cast<const uint2 *>(p.spos)[gs];
+        q.pxy = v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)}; q.pz = h2f(r.y & 0xffffu);
+    } else {
+        const float *sp = reinterpret_cast<const float *>(p.spos) + gs * 3;
+        q.pxy = v2f{sp[0], sp[1]}; q.pz = sp[2];
+    }
+    q.nxy = v2f{p.snrm[gs * 3], p.snrm[gs * 3 + 1]}; q.nz = p.snrm[gs * 3 + 2];
+    if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
+        const float2 uv = reinterpret_cast<const float2 *>(p.suv)[gs];
+        q.uv = v2f{uv.x, uv.y};
+    }
+    q.perm = p.perm[gs];
+    if constexpr (MORPH == kMorphFused1 || MORPH == kMorphFused4) {
+        const uint2 sl2 = p.ell[gs >> 6];            // slice of this wave-slot (wave-uniform)
+        q.rb = sl2.x + uint32_t(gs & 63); q.rlen = sl2.y;
+    }
+    if (q.cls == 0) {
+        q.b0 = uint32_t(p.skin1[th.skin1_off + s]) * 3;
+    } else if (q.cls == 1) {
+        const uint32_t i = th.skin2_off + (s - n1);
+        const uint32_t ids = p.skin2_ids[i];
+        q.b0 = (ids & 0xffffu) * 3; q.b1 = (ids >> 16) * 3;
+        q.w0 = p.skin2_w[i];
+    } else {
+        const uint32_t i = th.skin4_off + (s - n12);
+        const uint2 ids = p.skin4_ids[i];
+        const float4 w = p.skin4_w[i];
+        q.b0 = (ids.x & 0xffffu) * 3; q.b1 = (ids.x >> 16) * 3;
+        q.b2 = (ids.y & 0xffffu) * 3; q.b3 = (ids.y >> 16) * 3;
+        q.w0 = w.x; q.w1 = w.y; q.w2 = w.z; q.w3 = w.w;
+    }
+}
+
+// bone palettes of `count` instances (first one `inst0`, then every `istep`-th) -> LDS: only the tile's bones,
+// in the pair layout load_m12 reads.  One wave-instruction fetches ONE bone for 16 instances (lane = instance x
+// matrix row: sixteen 64-byte pieces); the bone id is wave-uniform, so it comes through the scalar cache and the
+// palette loads do not wait for a vector load of the bone list first -- one dependent round trip less in a
+// set-up phase that runs while the CU's memory pipeline is full of other workgroups' stores.
+template <int THREADS>
+__device__ __forceinline__ void stage_palettes(const DeformParams &p, const TileHdr &th, float4 *pal, uint32_t inst0,
+                                               uint32_t istep, uint32_t count, int tid) {
+    const uint32_t nbt = th.nbt;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(uint32_t(tid) >> 6), lane = uint32_t(tid) & 63u;
+    const uint32_t gl = lane >> 2, r = lane & 3u;
+    const uint32_t *bones = p.bone_list + th.bone_off;
+    for (uint32_t g0 = 0; g0 < count; g0 += 16) {
+        const uint32_t g = g0 + gl;
+        const bool on = g < count;
+        const float *src = p.palettes + size_t(inst0 + (on ? g : 0u) * istep) * p.nb * 16 + r * 4;
+        float *dst = reinterpret_cast<float *>(pal + size_t(g) * p.pal_stride);
+#pragma unroll 4
+        for (uint32_t lb = wave; lb < nbt; lb += THREADS / 64) {
+            const uint32_t bone = bones[lb];                 // wave-uniform: scalar load
+            if (on) {
+                const float4 row = *reinterpret_cast<const float4 *>(src + size_t(bone) * 16);
+                // entry = {m00 m01 | m10 m11} {m20 m21 | m30 m31} {m02 m12 | m22 m32}; this lane holds row r
+                float *e = dst + lb * 12;
+                *reinterpret_cast<float2 *>(e + (r >> 1) * 4 + (r & 1u) * 2) = make_float2(row.x, row.y);
+                e[8 + r] = row.z;
+            }
+        }
+    }
+}
+
+// One instance: skin the thread's slots with the palette at P (LDS), scatter the results to the LDS image `img`
+// (undoing the class sort), ONE workgroup barrier, then write the image out with coalesced 16-byte stores.
+// `inst` = the instance's index in the output arrays, cxy / cz = the (morphed) positions of the thread's slots.
+template <int THREADS, int LAYOUT, int VPT>
+__device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot (&sl)[VPT], const float4 *P,
+                                              unsigned char *img, uint32_t inst, uint32_t v0, uint32_t nvt,
+                                              const v2f (&cxy)[VPT], const float (&cz)[VPT], int tid) {
+    const size_t vbase = size_t(inst) * p.nv + v0;  // first output vertex of this tile
+    const bool al = p.out_aligned != 0;
+    const uint32_t sh4 = al ? uint32_t((vbase * 3) & 3) : 0u;
+    const uint32_t sh8 = al ? uint32_t((vbase * 3) & 7) : 0u;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const Slot &q = sl[k];
+        if (!q.act) continue;
+        M12 m;
+        if (q.cls == 0) {
+            m = load_m12(P, q.b0);
+        } else if (q.cls == 1) {
+            // Lerp(S[b1], S[b0])[w]  (poser_impl.inl:420-422, math_impl.inl:1246-1254)
+            const M12 a = load_m12(P, q.b1), e = load_m12(P, q.b0);
+            const float l = q.w0;
+            m = blend2(a, e, 1.0f - l, l);
+            // epsilon short-circuits: rare, so only waves that hold such a weight pay for them
+            const bool lo = l < kLerpLo, hi = l > kLerpHi;
+            if (__builtin_amdgcn_ballot_w64(lo || hi) != 0) {
+                if (lo) m = a;
+                else if (hi) m = e;
+            }
+        } else {
+            // ((S0*w0 + S1*w1) + S2*w2) + S3*w3, two palette entries in registers at a time: the scheduler would
+            // otherwise issue all twelve LDS reads first and hold four matrices (48 VGPRs) at once -- the peak
+            // of the kernel's register pressure
+            {
+                const M12 a = load_m12(P, q.b0), b = load_m12(P, q.b1);
+                m = mul_add(a, q.w0, b, q.w1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const M12 c = load_m12(P, q.b2);
+                m = add_mul(m, c, q.w2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const M12 d = load_m12(P, q.b3);
+                m = add_mul(m, d, q.w3);
+            }
+        }
+        v2f oxy, rxy;
+        float oz, rz;
+        xform_pos(m, cxy[k], cz[k], oxy, oz);
+        xform_nrm(m, q.nxy, q.nz, rxy, rz);
+        // pos_scale is a separate multiply after the transform (main.cpp:848-850); x*1.0f == x
+        oxy = oxy * p.pos_scale;
+        oz = oz * p.pos_scale;
+        if constexpr (LAYOUT == MMDX_OUT_SOA) {
+            float *A = reinterpret_cast<float *>(img) + sh4 + q.perm * 3;
+            float *B = reinterpret_cast<float *>(img + kSoaImgBytes) + sh4 + q.perm * 3;
+            A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
+            B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
+        } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
+            float4 *I = reinterpret_cast<float4 *>(img) + q.perm * 2;
+            I[0] = make_float4(oxy.x, oxy.y, oz, rxy.x);
+            I[1] = make_float4(rxy.y, rz, q.uv.x, q.uv.y);
+        } else {
+            unsigned short *A = reinterpret_cast<unsigned short *>(img) + sh8 + q.perm * 3;
+            float *B = reinterpret_cast<float *>(img + kP16ImgBytes) + sh4 + q.perm * 3;
+            A[0] = f2h(oxy.x); A[1] = f2h(oxy.y); A[2] = f2h(oz);
+            B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
+        }
+    }
+    __syncthreads();
+    const bool fast = al && nvt == kTileVerts && sh4 == 0 && sh8 == 0;
+    if constexpr (LAYOUT == MMDX_OUT_SOA) {
+        float *oa = reinterpret_cast<float *>(p.out_a), *ob = reinterpret_cast<float *>(p.out_b);
+        if (fast)
+            copy_out_fast<THREADS, kTileVerts * 12 / 16, kTileVerts * 12 / 16>(
+                img, kSoaImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
+                reinterpret_cast<float4 *>(ob + vbase * 3), tid);
+        else
+            copy_out2<THREADS, float, float>(img, oa, vbase * 3, sh4, nvt * 3, img + kSoaImgBytes, ob,
+                                             vbase * 3, sh4, nvt * 3, al, tid);
+    } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
+        float *oa = reinterpret_cast<float *>(p.out_a);
+        if (fast)
+            copy_out_fast<THREADS, kTileVerts * 32 / 16, 0>(
+                img, 0u, reinterpret_cast<float4 *>(oa + vbase * 8), nullptr, tid);
+        else
+            copy_out2<THREADS, float, float>(img, oa, vbase * 8, 0u, nvt * 8, img, oa, 0, 0u, 0u, al,
+                                             tid);
+    } else {
+        unsigned short *oa = reinterpret_cast<unsigned short *>(p.out_a);
+        float *ob = reinterpret_cast<float *>(p.out_b);
+        if (fast)
+            copy_out_fast<THREADS, kTileVerts * 6 / 16, kTileVerts * 12 / 16>(
+                img, kP16ImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
+                reinterpret_cast<float4 *>(ob + vbase * 3), tid);
+        else
+            copy_out2<THREADS, unsigned short, float>(img, oa, vbase * 3, sh8, nvt * 3,
+                                                      img + kP16ImgBytes, ob, vbase * 3, sh4, nvt * 3,
+                                                      al, tid);
+    }
+}
+
 // ---- the deformation kernel ----------------------------------------------------------------------
 // THREADS = 512: one sorted slot per lane, 8 waves per workgroup; THREADS = 256: two slots per lane.
 template <int THREADS, int LAYOUT, int MORPH, bool F16>
@@ -257,28 +512,10 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     constexpr int VPT = int(kTileVerts) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    // XCD-aware work mapping (speed only, never correctness): workgroup ids are dealt round-robin over
-    // the 8 XCDs, each with a private 4 MiB L2.  XCD x gets a CONTIGUOUS range of tiles for all
-    // instance groups, tile index fastest, so the ~96 workgroups resident on one XCD are (its ~12 tiles)
-    // x (8 groups): a tile's static streams and the palette rows neighbouring tiles share are fetched
-    // into that L2 once instead of once per XCD.  Tiles left over by ntiles % 8 are split by groups.
     uint32_t tile, grp;
-    {
-        const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
-        const uint32_t T = p.ntiles >> 3, main_count = T * p.ngroups;
-        if (k < main_count) {
-            grp = k / T;
-            tile = xcd * T + (k - grp * T);
-        } else {
-            const uint32_t r = xcd * p.rem_per_xcd + (k - main_count);
-            if (r >= (p.ntiles & 7u) * p.ngroups) return;       // padding workgroup
-            const uint32_t rt = r / p.ngroups;
-            tile = 8u * T + rt;
-            grp = r - rt * p.ngroups;
-        }
-    }
+    if (!map_workgroup(p, tile, grp)) return;       // padding workgroup
     const TileHdr &th = p.tiles[tile];
-    const uint32_t v0 = th.v0, nvt = th.nv, n1 = th.n1, n12 = th.n1 + th.n2, nbt = th.nbt;
+    const uint32_t v0 = th.v0, nvt = th.nv;
     // Instances of this workgroup.  Blocked: grp*group + g.  Interleaved (crowd modes): g*ngroups + grp,
     // so that the workgroups running at the same time (neighbouring grp) write NEIGHBOURING instances:
     // chip-wide the stores then sweep a few contiguous megabytes of each output array, like a linear
@@ -293,17 +530,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     constexpr uint32_t kStage = stage_bytes(LAYOUT);
 
     // 1. bone palettes of the group's instances -> LDS: only the tile's bones, in the pair layout
-    for (uint32_t idx = tid; idx < gcount * nbt; idx += THREADS) {
-        const uint32_t g = idx / nbt, lb = idx - g * nbt;
-        const uint32_t bone = p.bone_list[th.bone_off + lb];
-        const float4 *src =
-            reinterpret_cast<const float4 *>(p.palettes + (size_t(inst0 + g * istep) * p.nb + bone) * 16);
-        const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-        float4 *dst = pal + size_t(g) * p.pal_stride + lb * 3;
-        dst[0] = make_float4(r0.x, r0.y, r1.x, r1.y);
-        dst[1] = make_float4(r2.x, r2.y, r3.x, r3.y);
-        dst[2] = make_float4(r0.z, r1.z, r2.z, r3.z);
-    }
+    stage_palettes<THREADS>(p, th, pal, inst0, istep, gcount, tid);
     // 2. morph slot weights of the group -> LDS
     if constexpr (MORPH == kMorphFused1) {
         float *wl = reinterpret_cast<float *>(smem + p.w_off);
@@ -319,144 +546,15 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     // 3. static per-vertex data -> registers (sorted slot s = tid + k*THREADS)
     Slot sl[VPT];
 #pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-        Slot &q = sl[k];
-        const uint32_t s = uint32_t(tid) + uint32_t(k) * THREADS;
-        q.act = s < nvt;
-        q.cls = s < n1 ? 0 : (s < n12 ? 1 : 2);
-        q.pxy = q.nxy = q.uv = v2f{0.f, 0.f};
-        q.pz = q.nz = 0.f;
-        q.w0 = q.w1 = q.w2 = q.w3 = 0.f;
-        q.b0 = q.b1 = q.b2 = q.b3 = 0;
-        q.perm = 0; q.rb = q.rlen = 0;
-        if (q.act) {
-            const size_t gs = size_t(v0) + s;
-            if constexpr (MORPH == kMorphShared) {
-                q.pxy = v2f{p.morphed[gs * 3], p.morphed[gs * 3 + 1]}; q.pz = p.morphed[gs * 3 + 2];
-            } else if constexpr (F16) {
-                const uint2 r = reinterpret_cast<const uint2 *>(p.spos)[gs];
-                q.pxy = v2f{h2f(r.x & 0xffffu), h2f(r.x >> 16)}; q.pz = h2f(r.y & 0xffffu);
-            } else {
-                const float *sp = reinterpret_cast<const float *>(p.spos) + gs * 3;
-                q.pxy = v2f{sp[0], sp[1]}; q.pz = sp[2];
-            }
-            q.nxy = v2f{p.snrm[gs * 3], p.snrm[gs * 3 + 1]}; q.nz = p.snrm[gs * 3 + 2];
-            if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
-                const float2 uv = reinterpret_cast<const float2 *>(p.suv)[gs];
-                q.uv = v2f{uv.x, uv.y};
-            }
-            q.perm = p.perm[gs];
-            if constexpr (MORPH == kMorphFused1 || MORPH == kMorphFused4) {
-                const uint2 sl2 = p.ell[gs >> 6];            // slice of this wave-slot (wave-uniform)
-                q.rb = sl2.x + uint32_t(gs & 63); q.rlen = sl2.y;
-            }
-            if (q.cls == 0) {
-                q.b0 = uint32_t(p.skin1[th.skin1_off + s]) * 3;
-            } else if (q.cls == 1) {
-                const uint32_t i = th.skin2_off + (s - n1);
-                const uint32_t ids = p.skin2_ids[i];
-                q.b0 = (ids & 0xffffu) * 3; q.b1 = (ids >> 16) * 3;
-                q.w0 = p.skin2_w[i];
-            } else {
-                const uint32_t i = th.skin4_off + (s - n12);
-                const uint2 ids = p.skin4_ids[i];
-                const float4 w = p.skin4_w[i];
-                q.b0 = (ids.x & 0xffffu) * 3; q.b1 = (ids.x >> 16) * 3;
-                q.b2 = (ids.y & 0xffffu) * 3; q.b3 = (ids.y >> 16) * 3;
-                q.w0 = w.x; q.w1 = w.y; q.w2 = w.z; q.w3 = w.w;
-            }
-        }
-    }
+    for (int k = 0; k < VPT; ++k) load_slot<LAYOUT, MORPH, F16>(p, th, uint32_t(tid) + uint32_t(k) * THREADS, sl[k]);
     __syncthreads();
 
     uint32_t buf = 0;
-    // one instance: skin the thread's slots, scatter to the LDS image, write the image out
+    // the image is double buffered: the next instance writes the other one, so one barrier per instance is enough
     auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT]) {
-        const float4 *P = pal + size_t(g) * p.pal_stride;
-        unsigned char *img = stage + buf * kStage;
-        const size_t vbase = size_t(inst0 + g * istep) * p.nv + v0;  // first output vertex of this tile
-        const bool al = p.out_aligned != 0;
-        const uint32_t sh4 = al ? uint32_t((vbase * 3) & 3) : 0u;
-        const uint32_t sh8 = al ? uint32_t((vbase * 3) & 7) : 0u;
-#pragma unroll
-        for (int k = 0; k < VPT; ++k) {
-            const Slot &q = sl[k];
-            if (!q.act) continue;
-            M12 m;
-            if (q.cls == 0) {
-                m = load_m12(P, q.b0);
-            } else if (q.cls == 1) {
-                // Lerp(S[b1], S[b0])[w]  (poser_impl.inl:420-422, math_impl.inl:1246-1254)
-                const M12 a = load_m12(P, q.b1), e = load_m12(P, q.b0);
-                const float l = q.w0;
-                m = blend2(a, e, 1.0f - l, l);
-                // epsilon short-circuits: rare, so only waves that hold such a weight pay for them
-                const bool lo = l < kLerpLo, hi = l > kLerpHi;
-                if (__builtin_amdgcn_ballot_w64(lo || hi) != 0) {
-                    if (lo) m = a;
-                    else if (hi) m = e;
-                }
-            } else {
-                const M12 a = load_m12(P, q.b0), b = load_m12(P, q.b1), c = load_m12(P, q.b2),
-                          d = load_m12(P, q.b3);
-                m = blend4(a, b, c, d, q.w0, q.w1, q.w2, q.w3);
-            }
-            v2f oxy, rxy;
-            float oz, rz;
-            xform_pos(m, cxy[k], cz[k], oxy, oz);
-            xform_nrm(m, q.nxy, q.nz, rxy, rz);
-            // pos_scale is a separate multiply after the transform (main.cpp:848-850); x*1.0f == x
-            oxy = oxy * p.pos_scale;
-            oz = oz * p.pos_scale;
-            if constexpr (LAYOUT == MMDX_OUT_SOA) {
-                float *A = reinterpret_cast<float *>(img) + sh4 + q.perm * 3;
-                float *B = reinterpret_cast<float *>(img + kSoaImgBytes) + sh4 + q.perm * 3;
-                A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
-                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
-            } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
-                float4 *I = reinterpret_cast<float4 *>(img) + q.perm * 2;
-                I[0] = make_float4(oxy.x, oxy.y, oz, rxy.x);
-                I[1] = make_float4(rxy.y, rz, q.uv.x, q.uv.y);
-            } else {
-                unsigned short *A = reinterpret_cast<unsigned short *>(img) + sh8 + q.perm * 3;
-                float *B = reinterpret_cast<float *>(img + kP16ImgBytes) + sh4 + q.perm * 3;
-                A[0] = f2h(oxy.x); A[1] = f2h(oxy.y); A[2] = f2h(oz);
-                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
-            }
-        }
-        __syncthreads();
-        const bool fast = al && nvt == kTileVerts && sh4 == 0 && sh8 == 0;
-        if constexpr (LAYOUT == MMDX_OUT_SOA) {
-            float *oa = reinterpret_cast<float *>(p.out_a), *ob = reinterpret_cast<float *>(p.out_b);
-            if (fast)
-                copy_out_fast<THREADS, kTileVerts * 12 / 16, kTileVerts * 12 / 16>(
-                    img, kSoaImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
-                    reinterpret_cast<float4 *>(ob + vbase * 3), tid);
-            else
-                copy_out2<THREADS, float, float>(img, oa, vbase * 3, sh4, nvt * 3, img + kSoaImgBytes, ob,
-                                                 vbase * 3, sh4, nvt * 3, al, tid);
-        } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
-            float *oa = reinterpret_cast<float *>(p.out_a);
-            if (fast)
-                copy_out_fast<THREADS, kTileVerts * 32 / 16, 0>(
-                    img, 0u, reinterpret_cast<float4 *>(oa + vbase * 8), nullptr, tid);
-            else
-                copy_out2<THREADS, float, float>(img, oa, vbase * 8, 0u, nvt * 8, img, oa, 0, 0u, 0u, al,
-                                                 tid);
-        } else {
-            unsigned short *oa = reinterpret_cast<unsigned short *>(p.out_a);
-            float *ob = reinterpret_cast<float *>(p.out_b);
-            if (fast)
-                copy_out_fast<THREADS, kTileVerts * 6 / 16, kTileVerts * 12 / 16>(
-                    img, kP16ImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
-                    reinterpret_cast<float4 *>(ob + vbase * 3), tid);
-            else
-                copy_out2<THREADS, unsigned short, float>(img, oa, vbase * 3, sh8, nvt * 3,
-                                                          img + kP16ImgBytes, ob, vbase * 3, sh4, nvt * 3,
-                                                          al, tid);
-        }
-        buf ^= 1u;  // double-buffered image: the next instance writes the other one, so one barrier
-                    // per instance is enough
+        skin_instance<THREADS, LAYOUT, VPT>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
+                                            inst0 + g * istep, v0, nvt, cxy, cz, tid);
+        buf ^= 1u;
     };
 
     // 4. the group's instances
@@ -476,9 +574,9 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         for (int k = 0; k < VPT; ++k) {
             v2f dxy = v2f{0.f, 0.f};
             float dz = 0.f;
-            for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
+            for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                 const float w = wl[slot];
-                if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
+                if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
             });
             cxy[k] = sl[k].pxy + dxy; cz[k] = sl[k].pz + dz;
         }
@@ -488,7 +586,10 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         // a vertex's morph row then serves 4*kQuads instances, so the table is walked (and its L2 latency paid)
         // that much less often.  One slot per lane (512 threads) has the registers for two quads; two slots per
         // lane do not (a third wave per SIMD is worth more there: measured).  A missing second quad is staged as
-        // zeros: weight +0 adds nothing, bit for bit.
+        // zeros: weight +0 adds nothing, bit for bit.  The accumulators pair x with y of ONE instance; pairing two
+        // instances per component instead (three packed multiply-adds per entry and instance pair, a quarter fewer
+        // instructions) measured 10 % slower: v_pk_mul_f32 / v_pk_add_f32 occupy the SIMD for two passes, so the
+        // arithmetic time is the same and the position fix-up comes on top.
         constexpr int kQuads = VPT == 1 ? 2 : 1, kPack = 4 * kQuads;
         float4 *wq = reinterpret_cast<float4 *>(smem + p.w_off);
         const uint32_t wstride = p.ns + 1;
@@ -521,16 +622,18 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
                     // the image bit-for-bit unchanged: the skip needs no branch.
-                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
+                        const v2f oxy = v2f{ox, oy};
 #pragma unroll
                         for (int j = 0; j < kPack; ++j) { dxy[k][j] += oxy * w[j]; dz[k][j] += oz * w[j]; }
                     });
                 } else {
-                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](v2f oxy, float oz, uint32_t slot) {
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
+                        const v2f oxy = v2f{ox, oy};
 #pragma unroll
                         for (int j = 0; j < kPack; ++j)
                             if (!(w[j] < kMorphEps)) { dxy[k][j] += oxy * w[j]; dz[k][j] += oz * w[j]; }
@@ -581,9 +684,9 @@ __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParam
     v2f dxy = v2f{0.f, 0.f};
     float dz = 0.f;
     const uint2 sl2 = p.ell[gs >> 6];
-    for_row<F16>(p.entries, sl2.x + uint32_t(gs & 63), sl2.y, [&](v2f oxy, float oz, uint32_t slot) {
+    for_row<F16>(p.entries, sl2.x + uint32_t(gs & 63), sl2.y, [&](float ox, float oy, float oz, uint32_t slot) {
         const float w = wsl[slot];
-        if (!(w < kMorphEps)) { dxy = dxy + oxy * w; dz = dz + oz * w; }
+        if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
     });
     p.morphed[gs * 3] = bx + dxy.x;
     p.morphed[gs * 3 + 1] = by + dxy.y;

@@ -52,6 +52,7 @@ struct Plan {
     uint32_t ntiles = 0;
     uint32_t n1 = 0, n2 = 0, n4 = 0;
     uint32_t max_tile_bones = 0;
+    uint32_t max_tile_entries = 0;   // largest tile's slice of the morph table, in entries incl. padding
     bool f16 = false;
     bool finite_offsets = true;   // no inf/NaN among the vertex-morph offsets (after f16 rounding)
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""The per-instance-morph ("fused gather") workloads alone: config 2 x 64 frames, config 5 x 64 frames (f16
+positions), config 3' (1024-instance crowd, every instance its own morph weights).  Prints ms per call and the
+algorithmic-bytes rate; small enough to run under rocprofv3 (--kernel-trace / --pmc passes).
+
+    python tools/fused_bench.py [c2] [c5] [c3p] [--iters N]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
+from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
+
+HBM = 8000.0
+
+
+def run(name, model, ni, frames, layout, iters, f16=False):
+    dm = DeformModel(model, f16_positions=f16)
+    pals = synth.make_palettes(model, frames)
+    rates = synth.morph_weights(model.nm, frames)
+    d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
+    sa, sb = dm.out_sizes(layout, ni)
+    d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+    ms = bench.time_calls(dm, lambda: dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, layout, flags), iters)
+    i = dm.info
+    if f16:
+        static = model.nv * (6 + 12 + 1) + i.n_bdef1 * 2 + i.n_bdef2 * 8 + i.n_bdef4 * 24
+        table, outb = i.n_entries * 10, 18
+    else:
+        static = model.nv * 25 + i.n_bdef1 * 2 + i.n_bdef2 * 8 + i.n_bdef4 * 24
+        table, outb = i.n_entries * 16, 24
+    b = static + table + ni * (model.nv * outb + model.nb * 48 + model.nm * 4)
+    print(f"{name:8s} ni={ni:5d} {ms * 1e3:9.1f} us  {ni * model.nv / (ms * 1e-3) / 1e9:8.2f} Gverts/s  "
+          f"{b / (ms * 1e-3) / 1e9:7.0f} GB/s = {b / (ms * 1e-3) / 1e9 / HBM:.3f} of 8 TB/s   "
+          f"(entries {i.n_entries} padded {i.n_entries_padded}, slots {i.n_slots}, tile bones {i.max_tile_bones})", flush=True)
+    for x in (d_pal, d_w, d_a, d_b):
+        x.free()
+    dm.close()
+
+
+def main():
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c2", "c5", "c3p"]
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
+    if "c2" in which or "c3p" in which:
+        m = synth.make_config("config2_50k")
+        if "c2" in which:
+            run("c2x64", m, 64, np.arange(64), api.OUT_SOA, iters)
+        if "c3p" in which:
+            run("c3prime", m, 1024, (np.arange(1024) * 7) % 600, api.OUT_SOA, max(iters // 2, 5))
+    if "c5" in which:
+        m5 = synth.make_config("config5_256k")
+        run("c5x64", m5, 64, np.arange(64), api.OUT_SOA_POS16, iters, f16=True)
+
+
+if __name__ == "__main__":
+    main()
