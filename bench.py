@@ -273,6 +273,27 @@ def main():
             result["roofline"]["measured_store_pattern_GBs"] = ni * model.nv * 24 / (ms.value * 1e-3) / 1e9
             step()      # leave real results in the output buffers
             result["roofline"]["trace_segments"].append(["trailing", 1])
+        # What a caller sees who simply hipMallocs the output arrays (first placement, no probing): the same K steps
+        # into plainly allocated arrays, next to the headline's placement-probed ones.  On MI355X about six placements
+        # in seven store ~25 % slower for this two-array pattern; the headline says how many
+        # tries its placement took.
+        if not args.plain_alloc and placement.get("tries", 1) >= 1:
+            p_a, p_b, p_info = dm.alloc_outputs(layout, ni, 1)
+
+            def plain_step():
+                dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, p_a.ptr, p_b.ptr if p_b else None, layout, flags, pos_scale)
+            timed_batch(plain_step, 20)
+            pl_ms = timed_batch(plain_step, args.steps)
+            pl = {"ms_per_step": pl_ms, "vertices_per_s": ni * model.nv / (pl_ms * 1e-3),
+                  "step_frac": step_bytes / (pl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if layout == api.OUT_SOA and model.nv % 4 == 0:
+                api.check(api.lib().mmdx_bench_store_pattern(p_a.ptr, p_b.ptr, model.nv, ni, 10, C.byref(ms)))
+                pl["store_pattern_GBs"] = ni * model.nv * 24 / (ms.value * 1e-3) / 1e9
+            result["roofline"]["plain_alloc"] = pl
+            result["roofline"]["trace_segments"].append(["plain_alloc", 20 + args.steps])
+            p_a.free()
+            if p_b:
+                p_b.free()
 
     # ---- CPU baseline: rank 0, N=1 only ------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
