@@ -432,13 +432,20 @@ typedef struct mmdx_skeleton_desc {           /* e.g. straight from mmdx_pmx_get
      * model's morph table as in mmdx_model_desc; only group (0) and bone (2) morphs are read.  n_morphs
      * == 0 / NULL: no bone morphs (morph_rotation_ = identity, morph_translation_ = 0).                */
     uint32_t n_morphs;
-    uint32_t reserved0;
+    uint32_t create_flags;                    /* MMDX_SKELETON_*                                      */
     const int32_t *morph_type;                /* [n_morphs] PMX morph type                            */
     const uint32_t *morph_offset;             /* [n_morphs+1]                                         */
     const uint32_t *morph_index;              /* [E] group: morph index; bone: bone index             */
     const float *morph_value;                 /* [E][3] group: rate in [0]; bone: translation         */
     const float *morph_rotation;              /* [E][4] bone: rotation xyzw; NULL = identity          */
 } mmdx_skeleton_desc;
+
+enum {
+    MMDX_SKELETON_PHYSICS_SEAM = 1u << 0      /* the skeleton will be solved in two steps with a physics reactor's
+                                                 writes in between (mmdx_skeleton_solve_pre / _post): compiles the
+                                                 ordered solver, which keeps per-bone state between the steps, for
+                                                 rigs without IK / append bones too                              */
+};
 
 typedef struct mmdx_skeleton_info {
     uint32_t struct_size;
@@ -472,6 +479,36 @@ MMDX_API mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t skeleton, mmdx_model_t 
  * MMDX_WEIGHTS_SHARED; device pointer with MMDX_WEIGHTS_ON_DEVICE) are the raw per-frame morph rates, the
  * ones mmdx_deform_batched takes.  Bone-morph rotations go through SLerp, i.e. through the device's double
  * acos / sin like the reference's through the host's.  NULL weights = mmdx_skeleton_solve. */
+/* ---- the physics seam ---------------------------------------------------------------------------------
+ * The reference's frame is PrePhysicsPosing -> PhysicsReactor::React -> PostPhysicsPosing (main.cpp:1801-1810):
+ * after the pre-physics bone list the reactor (Bullet, on the host) overwrites the skinning matrix of every bone one
+ * of its bodies moved (PoserMotionState::Synchronize, mmd-bullet_impl.inl:34-40) and re-derives local_matrix_ of
+ * the "strict" ones from it -- keeping the bone's own translation -- before it recomputes their skinning matrix
+ * (Fix, :42-56); the post-physics bones then hang off those local matrices.  Two calls reproduce that:
+ *   mmdx_skeleton_solve_pre   reset + bone morphs + the pre-physics list; out_palettes rows of the pre-physics bones
+ *                             are written (what the reactor's kinematic bodies read), the others are unspecified;
+ *   (the host steps its physics)
+ *   mmdx_skeleton_solve_post  Synchronize for all listed bones, then Fix for the strict ones in list order, then the
+ *                             post-physics list; out_palettes (the SAME array the pre step wrote) receives the
+ *                             overridden rows and the post-physics bones' rows.
+ * The skeleton must have been created with MMDX_SKELETON_PHYSICS_SEAM; n_instances must match between the two
+ * calls.  Fix uses Matrix4f::Inverse's Gauss-Jordan elimination step for step (L/util/math_impl.inl:822-897):
+ * bit-exact against libmmd like the rest of the solve. */
+typedef struct mmdx_physics_overrides {
+    uint32_t struct_size;
+    uint32_t n_bones;                         /* K bones physics moved (the same set for every instance)         */
+    const int32_t *bone;                      /* [K] host                                                        */
+    const uint8_t *strict;                    /* [K] host, non-zero: Fix() applies; NULL = none                  */
+    const float *skinning;                    /* [NI][K][16] the bodies' transforms as skinning matrices; host, or
+                                                 device with MMDX_OVERRIDES_ON_DEVICE                            */
+} mmdx_physics_overrides;
+enum { MMDX_OVERRIDES_ON_DEVICE = 1u << 5 };
+MMDX_API mmdx_status mmdx_skeleton_solve_pre(mmdx_skeleton_t skeleton, mmdx_model_t model, uint32_t n_instances,
+                                             const float *poses, const float *morph_weights, uint32_t flags,
+                                             float *out_palettes);
+MMDX_API mmdx_status mmdx_skeleton_solve_post(mmdx_skeleton_t skeleton, mmdx_model_t model, uint32_t n_instances,
+                                              const mmdx_physics_overrides *overrides /* may be NULL */,
+                                              uint32_t flags, float *out_palettes);
 MMDX_API mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t skeleton, mmdx_model_t model,
                                                  uint32_t n_instances, const float *poses,
                                                  const float *morph_weights, uint32_t flags,

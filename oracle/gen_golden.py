@@ -450,5 +450,33 @@ def main():
     print(f"{'g13_config1_checksums':28s} 600 frames  {os.path.getsize(path) / 1024:7.1f} KB")
 
 
+def gen_physics_seam():
+    """Physics-seam fixture: a rig with post-physics bones, IK chains and append bones; libmmd's palettes for random
+    poses when a reactor's Synchronize / Fix writes sit between PrePhysicsPosing and PostPhysicsPosing
+    (oracle/ref_harness.cpp mmdref_pose_physics; the case is tests/test_physics_seam.py's physics_case)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.test_physics_seam import physics_case, random_transforms
+    from tests.test_rig import random_poses
+    nb, seed, n_ik, n_app = 64, 11, 3, 5
+    rig, over, strict, rng = physics_case(nb, seed, n_ik, n_app)
+    rest, parent, level, flags, ap, ar, ik = rig
+    poses = random_poses(10, nb, 1234)
+    xf = random_transforms(rng, 10, over.size)
+    ref = Reference.skeleton(rest, parent, level, flags, ap, ar, ik)
+    exp, pre = [], []
+    for i in range(poses.shape[0]):
+        e, p_ = ref.solve_physics(poses[i], over, strict, xf[i])
+        exp.append(e)
+        pre.append(p_)
+    ref.close()
+    np.savez_compressed(os.path.join(OUT, "rig_physics_expect.npz"), nb=nb, seed=seed, n_ik=n_ik, n_app=n_app,
+                        over=over, strict=strict, poses=poses, xf=xf, expect=np.stack(exp), expect_pre=np.stack(pre))
+    print(f"{'rig_physics_expect.npz':28s} {nb} bones, {over.size} physics bones ({int(strict.sum())} strict), 10 poses")
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-physics" in sys.argv:
+        gen_physics_seam()
+    else:
+        main()
+        gen_physics_seam()

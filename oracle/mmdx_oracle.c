@@ -694,6 +694,82 @@ static void apply_bone_morph(const bmorph_ctx *c, uint32_t m, float rate) {
  * ik_link_lo / ik_link_hi [L][3]; morph table (nm, type, off, index, value[E][3], rotation[E][4] or NULL) with
  * rates[nm] or nm == 0.  scratch = NB * (sizeof(bone_state_t) + 5) bytes.  Returns -1 when an IK link or
  * target is itself an IK bone (recursive solves are not restated) or an index is out of range. */
+/* Matrix4x4<T>::Inverse(), L/util/math_impl.inl:822-897: Gauss-Jordan on [M | I] with scaled partial pivoting
+ * (row i's scale = its largest |element|; a zero row or a zero last pivot gives the ZERO matrix), forward
+ * elimination, then the upper triangle is cleared column by column and every row divided by its pivot. */
+void mmdx_oracle_matrix_inverse(const float *in, float *out) {
+    float s[4][8], scale[4];
+    int row[4] = {0, 1, 2, 3};                              /* the reference swaps row pointers */
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { s[i][j] = in[4 * i + j]; s[i][j + 4] = i == j ? 1.0f : 0.0f; }
+    for (int i = 0; i < 4; ++i) {
+        scale[i] = fabsf(s[i][0]);
+        for (int j = 1; j < 4; ++j) { const float x = fabsf(s[i][j]); if (x > scale[i]) scale[i] = x; }
+        if (scale[i] == 0) { memset(out, 0, 64); return; }
+    }
+    for (int i = 0; i < 4; ++i) {
+        int pivot = i;
+        float best = fabsf(s[row[i]][i] / scale[i]);
+        for (int p = i + 1; p < 4; ++p) {
+            const float x = fabsf(s[row[p]][i] / scale[p]);
+            if (x > best) { best = x; pivot = p; }
+        }
+        if (pivot != i) {
+            const int r = row[i]; row[i] = row[pivot]; row[pivot] = r;
+            const float c = scale[i]; scale[i] = scale[pivot]; scale[pivot] = c;
+        }
+        for (int j = i + 1; j < 4; ++j) {
+            const float m = s[row[j]][i] / s[row[i]][i];
+            s[row[j]][i] = 0.0f;
+            for (int jj = i + 1; jj < 8; ++jj) s[row[j]][jj] -= m * s[row[i]][jj];
+        }
+    }
+    if (s[row[3]][3] == 0) { memset(out, 0, 64); return; }
+    for (int i = 1; i < 4; ++i)
+        for (int j = 0; j < i; ++j) {
+            const float m = s[row[j]][i] / s[row[i]][i];
+            for (int jj = j + 1; jj < 8; ++jj) s[row[j]][jj] -= m * s[row[i]][jj];
+        }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = s[row[i]][j + 4] / s[row[i]][i];
+}
+
+/* What BulletPhysicsReactor::React leaves in the poser between the two bone lists
+ * (L/../mmd-bullet/mmd-bullet_impl.inl:312-326): Synchronize (:34-40) -- the body's transform becomes the
+ * bone's skinning matrix -- for every moved bone, then Fix (:42-56) for the strict ones, in list order. */
+static void physics_fix(const solve_ctx *c, uint32_t b, float *skin /* [16] of bone b, in / out */) {
+    bone_state_t *s = &c->st[b];
+    float g[16], pl[16], inv[16];
+    mat_identity(g);                                        /* global_offset_matrix_inv_: + rest position */
+    g[12] = c->rest[3 * (size_t)b]; g[13] = c->rest[3 * (size_t)b + 1]; g[14] = c->rest[3 * (size_t)b + 2];
+    mat_mul(g, skin, s->local);
+    if (has_parent(c, b)) {
+        memcpy(pl, c->st[c->parent[b]].local, 64);
+        mmdx_oracle_matrix_inverse(pl, inv);
+        mat_mul(s->local, inv, s->local);
+    }
+    for (int k = 0; k < 3; ++k) {
+        const float off = has_parent(c, b) ? c->rest[3 * (size_t)b + k] - c->rest[3 * (size_t)c->parent[b] + k]
+                                           : c->rest[3 * (size_t)b + k];
+        s->local[12 + k] = s->total_tr[k] + off;
+    }
+    if (has_parent(c, b)) mat_mul(s->local, pl, s->local);
+    mat_identity(g);
+    g[12] = -c->rest[3 * (size_t)b]; g[13] = -c->rest[3 * (size_t)b + 1]; g[14] = -c->rest[3 * (size_t)b + 2];
+    mat_mul(g, s->local, skin);
+}
+
+static int bone_solve_impl(uint32_t nb, const float *rest, const int64_t *parent, const int32_t *level,
+                           const uint16_t *flags, const int64_t *append_parent, const float *append_ratio,
+                           const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
+                           const uint32_t *ik_link_off, const int64_t *ik_link_bone,
+                           const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi,
+                           uint32_t nm, const int32_t *morph_type, const uint32_t *morph_off,
+                           const uint32_t *morph_index, const float *morph_value, const float *morph_rotation,
+                           const float *rates, const float *poses, float *out, void *scratch,
+                           uint32_t n_over, const int64_t *over_bone, const uint8_t *over_strict,
+                           const float *over_skin, float *pre_out);
+
 int mmdx_oracle_bone_solve_full(uint32_t nb, const float *rest, const int64_t *parent, const int32_t *level,
                                 const uint16_t *flags, const int64_t *append_parent, const float *append_ratio,
                                 const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
@@ -703,6 +779,42 @@ int mmdx_oracle_bone_solve_full(uint32_t nb, const float *rest, const int64_t *p
                                 const uint32_t *morph_index, const float *morph_value, const float *morph_rotation,
                                 const float *rates,
                                 const float *poses, float *out, void *scratch) {
+    return bone_solve_impl(nb, rest, parent, level, flags, append_parent, append_ratio, ik_target, ik_loop, ik_angle,
+                           ik_link_off, ik_link_bone, ik_link_limited, ik_link_lo, ik_link_hi, nm, morph_type, morph_off,
+                           morph_index, morph_value, morph_rotation, rates, poses, out, scratch, 0, NULL, NULL, NULL, NULL);
+}
+
+/* The same frame with the physics reactor's writes between the two bone lists: over_skin [n_over][16] replace the
+ * skinning matrices of over_bone[] after the pre-physics list (out must have been... it is written here), Fix()
+ * for over_strict[k] != 0.  pre_out (may be NULL, [NB][16]) receives the palette as it stands after the
+ * pre-physics list (rows of post-physics bones: identity-derived values of a fresh poser are NOT modelled; they
+ * are left untouched). */
+int mmdx_oracle_bone_solve_physics(uint32_t nb, const float *rest, const int64_t *parent, const int32_t *level,
+                                   const uint16_t *flags, const int64_t *append_parent, const float *append_ratio,
+                                   const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
+                                   const uint32_t *ik_link_off, const int64_t *ik_link_bone,
+                                   const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi,
+                                   uint32_t nm, const int32_t *morph_type, const uint32_t *morph_off,
+                                   const uint32_t *morph_index, const float *morph_value, const float *morph_rotation,
+                                   const float *rates, const float *poses, float *out, void *scratch,
+                                   uint32_t n_over, const int64_t *over_bone, const uint8_t *over_strict,
+                                   const float *over_skin, float *pre_out) {
+    return bone_solve_impl(nb, rest, parent, level, flags, append_parent, append_ratio, ik_target, ik_loop, ik_angle,
+                           ik_link_off, ik_link_bone, ik_link_limited, ik_link_lo, ik_link_hi, nm, morph_type, morph_off,
+                           morph_index, morph_value, morph_rotation, rates, poses, out, scratch, n_over, over_bone,
+                           over_strict, over_skin, pre_out);
+}
+
+static int bone_solve_impl(uint32_t nb, const float *rest, const int64_t *parent, const int32_t *level,
+                           const uint16_t *flags, const int64_t *append_parent, const float *append_ratio,
+                           const int64_t *ik_target, const int32_t *ik_loop, const float *ik_angle,
+                           const uint32_t *ik_link_off, const int64_t *ik_link_bone,
+                           const uint8_t *ik_link_limited, const float *ik_link_lo, const float *ik_link_hi,
+                           uint32_t nm, const int32_t *morph_type, const uint32_t *morph_off,
+                           const uint32_t *morph_index, const float *morph_value, const float *morph_rotation,
+                           const float *rates, const float *poses, float *out, void *scratch,
+                           uint32_t n_over, const int64_t *over_bone, const uint8_t *over_strict,
+                           const float *over_skin, float *pre_out) {
     bone_state_t *st = (bone_state_t *)scratch;
     uint32_t *order = (uint32_t *)(st + nb);
     uint8_t *is_link = (uint8_t *)(order + nb);
@@ -756,6 +868,15 @@ int mmdx_oracle_bone_solve_full(uint32_t nb, const float *rest, const int64_t *p
             mat_identity(g);
             g[12] = -rest[3 * (size_t)b]; g[13] = -rest[3 * (size_t)b + 1]; g[14] = -rest[3 * (size_t)b + 2];
             mat_mul(g, st[b].local, out + 16 * (size_t)b);
+        }
+        if (pass == 0) {
+            if (pre_out) memcpy(pre_out, out, (size_t)nb * 64);
+            for (uint32_t k = 0; k < n_over; ++k) {
+                if (over_bone[k] < 0 || (uint64_t)over_bone[k] >= nb) return -1;
+                memcpy(out + 16 * (size_t)over_bone[k], over_skin + 16 * (size_t)k, 64);          /* Synchronize */
+            }
+            for (uint32_t k = 0; k < n_over; ++k)
+                if (over_strict && over_strict[k]) physics_fix(&c, (uint32_t)over_bone[k], out + 16 * (size_t)over_bone[k]);
         }
     }
     return 0;

@@ -169,6 +169,49 @@ class Oracle:
             raise ValueError("oracle bone solve: nested IK or an index out of range")
         return out
 
+    def bone_solve_physics(self, rest, parent, poses, over_bone, over_strict, over_skin, level=None, flags=None,
+                           append_parent=None, append_ratio=None, ik=None, morphs=None, rates=None):
+        """The bone solve with the physics reactor's writes between the two bone lists (main.cpp:1801-1810):
+        over_skin f32 [K,16] replace the skinning matrices of over_bone [K] after the pre-physics list, Fix() is
+        applied where over_strict [K] is non-zero.  Returns (palette f32 [NB,16], palette after the pre-physics list)."""
+        rest = _c(rest, np.float32).reshape(-1, 3)
+        nb = rest.shape[0]
+        arrs = [rest, _c(parent, np.int64).reshape(nb),
+                _c(level, np.int32).reshape(nb) if level is not None else None,
+                _c(flags, np.uint16).reshape(nb) if flags is not None else np.zeros(nb, np.uint16),
+                _c(append_parent, np.int64).reshape(nb) if append_parent is not None else None,
+                _c(append_ratio, np.float32).reshape(nb) if append_ratio is not None else None] + ik_arrays(ik)
+        types = [C.c_float, C.c_int64, C.c_int32, C.c_uint16, C.c_int64, C.c_float] + IK_TYPES
+        poses = _c(poses, np.float32).reshape(nb, 8)
+        out = np.zeros((nb, 16), np.float32)
+        pre = np.zeros((nb, 16), np.float32)
+        scratch = np.zeros(nb * 180 + 64, np.uint8)
+        nm, marr = morph_arrays(morphs if rates is not None else None)
+        r = _c(rates, np.float32).reshape(nm) if nm else None
+        ob = _c(over_bone, np.int64).reshape(-1)
+        k = ob.size
+        os_ = _c(over_strict, np.uint8).reshape(k) if k else np.zeros(1, np.uint8)
+        ok = _c(over_skin, np.float32).reshape(k, 16) if k else np.zeros((1, 16), np.float32)
+        if not k:
+            ob = np.zeros(1, np.int64)
+        self.lib.mmdx_oracle_bone_solve_physics.restype = C.c_int
+        rc = self.lib.mmdx_oracle_bone_solve_physics(
+            C.c_uint32(nb), *[_p(a, t) if a is not None else None for a, t in zip(arrs, types)],
+            C.c_uint32(nm), *[_p(a, t) if a is not None else None for a, t in zip(marr, MORPH_TYPES)],
+            _p(r, C.c_float) if r is not None else None,
+            _p(poses, C.c_float), _p(out, C.c_float), scratch.ctypes.data_as(C.c_void_p),
+            C.c_uint32(k), _p(ob, C.c_int64), _p(os_, C.c_uint8), _p(ok, C.c_float), _p(pre, C.c_float))
+        if rc != 0:
+            raise ValueError("oracle bone solve: nested IK or an index out of range")
+        return out, pre
+
+    def matrix_inverse(self, m):
+        """Matrix4f::Inverse() restated (L/util/math_impl.inl:822-897): f32 [16] -> f32 [16]."""
+        m = _c(m, np.float32).reshape(16)
+        out = np.zeros(16, np.float32)
+        self.lib.mmdx_oracle_matrix_inverse(_p(m, C.c_float), _p(out, C.c_float))
+        return out
+
     def trace_libm(self, fn, capacity=1 << 22):
         """Run fn() with the bone solve's transcendental calls recorded; returns u32 [N,4] records (function id,
         argument bits, second argument bits, result bits) -- see mmdx_oracle_trace_libm."""
@@ -347,6 +390,34 @@ class Reference:
         self.set_morphs(rates if rates is not None else np.zeros(self.model.nm, np.float32))
         self.pose()
         return self.get_palette()
+
+    def solve_physics(self, poses, over_bone, over_strict, over_skin, rates=None):
+        """The viewer's frame with a physics reactor in it: PrePhysicsPosing, the reactor's Synchronize / Fix writes
+        (over_skin [K,16] for over_bone [K], Fix where over_strict [K]), PostPhysicsPosing.
+        Returns (palette [NB,16], palette after PrePhysicsPosing)."""
+        poses = _c(poses, np.float32).reshape(self.model.nb, 8)
+        for b in range(self.model.nb):
+            self.set_bone_pose(b, poses[b, 0:3], poses[b, 4:8])
+        self.set_morphs(rates if rates is not None else np.zeros(self.model.nm, np.float32))
+        ob = _c(over_bone, np.int64).reshape(-1)
+        k = ob.size
+        os_ = _c(over_strict, np.uint8).reshape(k) if k else np.zeros(1, np.uint8)
+        ok = _c(over_skin, np.float32).reshape(k, 16) if k else np.zeros((1, 16), np.float32)
+        if not k:
+            ob = np.zeros(1, np.int64)
+        pre = np.zeros((self.model.nb, 16), np.float32)
+        self.lib.mmdref_pose_physics(self.h, C.c_uint32(k), _p(ob, C.c_int64), _p(os_, C.c_uint8), _p(ok, C.c_float),
+                                     _p(pre, C.c_float))
+        return self.get_palette(), pre
+
+    @staticmethod
+    def matrix_inverse(m):
+        """libmmd's Matrix4f::Inverse() itself."""
+        lib = C.CDLL(REF_SO)
+        m = _c(m, np.float32).reshape(16)
+        out = np.zeros(16, np.float32)
+        lib.mmdref_matrix_inverse(_p(m, C.c_float), _p(out, C.c_float))
+        return out
 
     @classmethod
     def from_pmd(cls, path: str) -> "Reference":

@@ -55,6 +55,27 @@ public:
     static float *Matrix(mmd::Poser &poser, size_t i) {
         return GetPoserBoneImage(poser, i).skinning_matrix_.v;
     }
+    // What BulletPhysicsReactor::React does to a poser once the world has been stepped
+    // (mmd-bullet_impl.inl:312-326): PoserMotionState::Synchronize of every body physics moved (:34-40, the body's
+    // transform becomes the bone's skinning matrix), then PoserMotionState::Fix of every strict one (:42-56).
+    // Bullet is not built here (the reactor needs the whole library); the bodies' transforms are the caller's
+    // input and the two small member functions are re-expressed with libmmd's OWN matrix operators
+    // (operator*, Inverse, the vector add) on libmmd's OWN BoneImage -- the arithmetic under test is the library's.
+    static void Synchronize(mmd::Poser &poser, size_t bone, const float *skinning) {
+        std::memcpy(GetPoserBoneImage(poser, bone).skinning_matrix_.v, skinning, 64);
+    }
+    static void Fix(mmd::Poser &poser, size_t bone) {
+        BoneImageReference t = GetPoserBoneImage(poser, bone);
+        mmd::Matrix4f parent_local;
+        t.local_matrix_ = t.global_offset_matrix_inv_ * t.skinning_matrix_;
+        if (t.has_parent_) {
+            parent_local = GetPoserBoneImage(poser, t.parent_).local_matrix_;
+            t.local_matrix_ = t.local_matrix_ * parent_local.Inverse();
+        }
+        t.local_matrix_.r.v[3].downgrade.vector3d = t.total_translation_ + t.local_offset_;
+        if (t.has_parent_) t.local_matrix_ = t.local_matrix_ * parent_local;
+        t.skinning_matrix_ = t.global_offset_matrix_ * t.local_matrix_;
+    }
 };
 
 struct Ref {
@@ -427,6 +448,32 @@ void mmdref_pose(void *h) {
     Ref *r = static_cast<Ref *>(h);
     r->poser->PrePhysicsPosing();
     r->poser->PostPhysicsPosing();
+}
+
+// The viewer's frame with a physics reactor in it (main.cpp:1801-1810): PrePhysicsPosing, React (see
+// PaletteTap::Synchronize / Fix: `skinning` [n][16] are the transforms physics produced for bones[0..n), strict[k]
+// != 0 marks the bodies Fix() applies to), PostPhysicsPosing.  pre_palette (may be NULL) receives the skinning
+// matrices as they stand after PrePhysicsPosing -- what the reactor's kinematic bodies read.
+void mmdref_pose_physics(void *h, uint32_t n, const int64_t *bones, const uint8_t *strict, const float *skinning,
+                         float *pre_palette) {
+    Ref *r = static_cast<Ref *>(h);
+    r->poser->PrePhysicsPosing();
+    if (pre_palette) {
+        const size_t nb = r->model.GetBoneNum();
+        for (size_t b = 0; b < nb; ++b) std::memcpy(pre_palette + 16 * b, PaletteTap::Matrix(*r->poser, b), 64);
+    }
+    for (uint32_t k = 0; k < n; ++k) PaletteTap::Synchronize(*r->poser, size_t(bones[k]), skinning + 16 * size_t(k));
+    for (uint32_t k = 0; k < n; ++k)
+        if (strict && strict[k]) PaletteTap::Fix(*r->poser, size_t(bones[k]));
+    r->poser->PostPhysicsPosing();
+}
+
+// Matrix4f::Inverse() alone (L/util/math_impl.inl:822-897), for pinning the restatements of it.
+void mmdref_matrix_inverse(const float *in, float *out) {
+    mmd::Matrix4f m;
+    std::memcpy(m.v, in, 64);
+    const mmd::Matrix4f r = m.Inverse();
+    std::memcpy(out, r.v, 64);
 }
 
 void mmdref_get_palette(void *h, float *out) {

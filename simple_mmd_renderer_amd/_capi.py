@@ -124,6 +124,9 @@ SIGNATURES = {
     "mmdx_skeleton_solve": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mmdx_skeleton_solve_morphed": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                                 C.c_void_p]),
+    "mmdx_skeleton_solve_pre": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                            C.c_void_p]),
+    "mmdx_skeleton_solve_post": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mmdx_skeleton_destroy": (None, [C.c_void_p]),
     "mmdx_pmx_get_skeleton_desc": (C.c_int32, [C.c_void_p, C.c_void_p]),
 }

@@ -79,23 +79,8 @@ __device__ __forceinline__ M12 blend2(const M12 &a, const M12 &b, float s1, floa
     r.q0 = a.q0 * s1 + b.q0 * l; r.q1 = a.q1 * s1 + b.q1 * l;
     return r;
 }
-// ((m0*w0 + m1*w1) + m2*w2) + m3*w3 per element (poser_impl.inl:433; weights not normalised)
-__device__ __forceinline__ v2f blend4_pair(v2f a, v2f b, v2f c, v2f d, float w0, float w1, float w2,
-                                           float w3) {
-    return ((a * w0 + b * w1) + c * w2) + d * w3;
-}
-__device__ __forceinline__ M12 blend4(const M12 &a, const M12 &b, const M12 &c, const M12 &d,
-                                      float w0, float w1, float w2, float w3) {
-    M12 r;
-    r.p0 = blend4_pair(a.p0, b.p0, c.p0, d.p0, w0, w1, w2, w3);
-    r.p1 = blend4_pair(a.p1, b.p1, c.p1, d.p1, w0, w1, w2, w3);
-    r.p2 = blend4_pair(a.p2, b.p2, c.p2, d.p2, w0, w1, w2, w3);
-    r.p3 = blend4_pair(a.p3, b.p3, c.p3, d.p3, w0, w1, w2, w3);
-    r.q0 = blend4_pair(a.q0, b.q0, c.q0, d.q0, w0, w1, w2, w3);
-    r.q1 = blend4_pair(a.q1, b.q1, c.q1, d.q1, w0, w1, w2, w3);
-    return r;
-}
-// the same blend in steps: a*wa + b*wb, then t + c*wc
+// BDEF4: ((m0*w0 + m1*w1) + m2*w2) + m3*w3 per element (poser_impl.inl:433; weights not normalised), evaluated in steps:
+// a*wa + b*wb, then t + c*wc
 __device__ __forceinline__ M12 mul_add(const M12 &a, float wa, const M12 &b, float wb) {
     M12 r;
     r.p0 = a.p0 * wa + b.p0 * wb; r.p1 = a.p1 * wa + b.p1 * wb;

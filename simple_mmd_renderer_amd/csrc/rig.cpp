@@ -205,6 +205,7 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
     if (nb && (!d.rest_position || !d.parent)) return bad(MMDX_ERR_INVALID_ARGUMENT, "rest_position / parent is NULL");
     out.nb = nb;
     std::vector<uint32_t> pre, post;
+    if (d.create_flags & MMDX_SKELETON_PHYSICS_SEAM) out.serial = true;   // per-bone state must survive between two calls
     auto flag = [&](uint32_t b) -> uint16_t { return d.flags ? d.flags[b] : uint16_t(0); };
     for (uint32_t b = 0; b < nb; ++b) {
         const uint16_t f = flag(b);

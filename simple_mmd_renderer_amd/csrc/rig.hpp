@@ -156,6 +156,18 @@ struct SerialParams {
     uint32_t n_rounds_pre, n_rounds;
     uint32_t fast_slots;                        // LDS window size in bones (0: no fast chain)
     uint32_t windows;                           // LDS windows per instance
+    uint32_t passes;                            // bit 0: reset + pre-physics list, bit 1: post-physics list
+};
+
+// The physics reactor's writes between the two lists (mmdx_skeleton_solve_post): Synchronize, then Fix.
+struct PhysicsParams {
+    const uint32_t *bone;                       // [k]
+    const uint8_t *strict;                      // [k]
+    const float *skinning;                      // [ni][k][16]
+    float *out;                                 // [ni][nb][16] palettes (rows of the listed bones are rewritten)
+    float *state;                               // the ordered solver's scratch
+    const BoneRec *bones;
+    uint32_t k, nb, ni;
 };
 
 }  // namespace mmdx

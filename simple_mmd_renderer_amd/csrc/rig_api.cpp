@@ -62,13 +62,21 @@ struct mmdx_skeleton_s {
     Buf local_offset, neg_rest, chain_off, chain, poses_in, out;
     Buf order, bones, iks, links, events, rounds, state;  // ordered solver
     Buf apps, app_chain, rates_in, morph_state;           // bone morphs
+    Buf over_bone, over_strict, over_skin;                // physics seam: the reactor's writes of one frame
+    uint32_t pre_instances = 0;                           // instances of the last mmdx_skeleton_solve_pre (0: none pending)
+    const float *pre_poses = nullptr;                     // the poses that call solved (device address)
+    const float *pre_morph = nullptr;
     void release_all() {
         for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &events, &rounds,
                        &state,
-                       &apps, &app_chain, &rates_in, &morph_state})
+                       &apps, &app_chain, &rates_in, &morph_state, &over_bone, &over_strict, &over_skin})
             b->release();
     }
 };
+
+static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances, const float *poses,
+                                  const float *morph_weights, uint32_t flags, float *out_palettes, uint32_t passes,
+                                  const mmdx_physics_overrides *ov);
 
 extern "C" {
 
@@ -197,7 +205,40 @@ mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t 
 mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances,
                                         const float *poses, const float *morph_weights, uint32_t flags,
                                         float *out_palettes) {
-    if (!s || !poses || !out_palettes || !n_instances)
+    return skeleton_solve(s, model, n_instances, poses, morph_weights, flags, out_palettes, 3u, nullptr);
+}
+
+mmdx_status mmdx_skeleton_solve_pre(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances, const float *poses,
+                                    const float *morph_weights, uint32_t flags, float *out_palettes) {
+    if (s && !s->plan.serial)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_skeleton_solve_pre needs a skeleton created with MMDX_SKELETON_PHYSICS_SEAM");
+    return skeleton_solve(s, model, n_instances, poses, morph_weights, flags, out_palettes, 1u, nullptr);
+}
+
+mmdx_status mmdx_skeleton_solve_post(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances,
+                                     const mmdx_physics_overrides *ov, uint32_t flags, float *out_palettes) {
+    if (s && !s->plan.serial)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_skeleton_solve_post needs a skeleton created with MMDX_SKELETON_PHYSICS_SEAM");
+    if (s && (!s->pre_instances || s->pre_instances != n_instances))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_skeleton_solve_post without a matching mmdx_skeleton_solve_pre");
+    if (ov) {
+        if (ov->struct_size != sizeof(mmdx_physics_overrides))
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_physics_overrides.struct_size mismatch");
+        if (ov->n_bones && (!ov->bone || !ov->skinning)) return fail(MMDX_ERR_INVALID_ARGUMENT, "overrides: bone / skinning is NULL");
+        for (uint32_t k = 0; s && k < ov->n_bones; ++k)
+            if (ov->bone[k] < 0 || uint32_t(ov->bone[k]) >= s->plan.nb)
+                return fail(MMDX_ERR_BAD_INDEX, "overrides: bone " + std::to_string(ov->bone[k]) + " out of range");
+    }
+    return skeleton_solve(s, model, n_instances, nullptr, nullptr, flags, out_palettes, 2u, ov);
+}
+
+}  // extern "C"
+
+// passes: bit 0 = reset + bone morphs + pre-physics list, bit 1 = (physics overrides +) post-physics list
+static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances, const float *poses,
+                                  const float *morph_weights, uint32_t flags, float *out_palettes, uint32_t passes,
+                                  const mmdx_physics_overrides *ov) {
+    if (!s || (!poses && (passes & 1u)) || !out_palettes || !n_instances)
         return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
     int device;
     hipStream_t st;
@@ -225,7 +266,10 @@ mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, u
     struct { const float *poses; float *out; } p;
     const size_t in_bytes = size_t(n_instances) * pl.nb * MMDX_POSE_FLOATS * sizeof(float);
     const size_t out_bytes = size_t(n_instances) * pl.nb * 16 * sizeof(float);
-    if (flags & MMDX_POSES_ON_DEVICE) {
+    if (!(passes & 1u)) {
+        p.poses = s->pre_poses;                      // the post-physics list re-reads the poses the pre step solved:
+                                                     // they must still be there (device poses are the caller's to keep)
+    } else if (flags & MMDX_POSES_ON_DEVICE) {
         p.poses = poses;
     } else {
         HIP_TRY(s->poses_in.ensure(in_bytes));
@@ -239,9 +283,9 @@ mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, u
         p.out = static_cast<float *>(s->out.ptr);
     }
     // bone morphs first: per-bone morph_translation_ / morph_rotation_ of every instance
-    const float *morph_state = nullptr;
+    const float *morph_state = (passes & 1u) ? nullptr : s->pre_morph;
     bool borrowed_rates = false;
-    if (morph_weights && !pl.apps.empty()) {
+    if ((passes & 1u) && morph_weights && !pl.apps.empty()) {
         const bool shared = (flags & MMDX_WEIGHTS_SHARED) != 0;
         const size_t rate_bytes = size_t(shared ? 1 : n_instances) * pl.nm * sizeof(float);
         BoneMorphParams mp;
@@ -277,7 +321,37 @@ mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, u
         sp.n_rounds_pre = pl.n_rounds_pre; sp.n_rounds = uint32_t(pl.rounds.size());
         sp.fast_slots = pl.fast_slots;
         sp.windows = pl.windows;
+        sp.passes = passes;
+        bool borrowed_over = false;
+        if ((passes & 2u) && ov && ov->n_bones) {     // the reactor's writes, between the two lists
+            PhysicsParams pp;
+            std::vector<uint32_t> ob(ov->bone, ov->bone + ov->n_bones);
+            std::vector<uint8_t> os(ov->n_bones, 0);
+            for (uint32_t k = 0; ov->strict && k < ov->n_bones; ++k) os[k] = ov->strict[k] ? 1 : 0;
+            HIP_TRY(s->over_bone.ensure(ob.size() * 4));
+            HIP_TRY(s->over_strict.ensure(os.size()));
+            HIP_TRY(hipMemcpyAsync(s->over_bone.ptr, ob.data(), ob.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s->over_strict.ptr, os.data(), os.size(), hipMemcpyHostToDevice, st));
+            const size_t xf_bytes = size_t(n_instances) * ov->n_bones * 64;
+            if (flags & MMDX_OVERRIDES_ON_DEVICE) {
+                pp.skinning = ov->skinning;
+            } else {
+                HIP_TRY(s->over_skin.ensure(xf_bytes));
+                HIP_TRY(hipMemcpyAsync(s->over_skin.ptr, ov->skinning, xf_bytes, hipMemcpyHostToDevice, st));
+                pp.skinning = static_cast<const float *>(s->over_skin.ptr);
+            }
+            HIP_TRY(hipStreamSynchronize(st));        // ob / os are locals: the copies above must have read them
+            borrowed_over = false;
+            pp.bone = static_cast<const uint32_t *>(s->over_bone.ptr);
+            pp.strict = static_cast<const uint8_t *>(s->over_strict.ptr);
+            pp.out = p.out; pp.state = sp.state; pp.bones = sp.bones;
+            pp.k = ov->n_bones; pp.nb = pl.nb; pp.ni = n_instances;
+            HIP_TRY(launch_physics_override(pp, st));
+        }
+        (void)borrowed_over;
         HIP_TRY(launch_skeleton_ordered(sp, st));
+        if (passes == 1u) { s->pre_instances = n_instances; s->pre_poses = p.poses; s->pre_morph = morph_state; }
+        else s->pre_instances = 0;
     } else {
         SkeletonParams fp;
         fp.morph = morph_state;
@@ -298,11 +372,9 @@ mmdx_status mmdx_skeleton_solve_morphed(mmdx_skeleton_t s, mmdx_model_t model, u
     return MMDX_OK;
 }
 
-void mmdx_skeleton_destroy(mmdx_skeleton_t s) {
+extern "C" void mmdx_skeleton_destroy(mmdx_skeleton_t s) {
     if (!s) return;
     if (s->device >= 0) (void)hipSetDevice(s->device);
     s->release_all();
     delete s;
 }
-
-}  // extern "C"

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordere
     auto *lds_consts = (__attribute__((address_space(3))) float *)chain_lds +
                        size_t(p.windows) * kSolveInstances * wf + slot * (kMaxFastLinks * kLinkConstFloats);
     const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(live ? inst : 0) * p.nb * 2;
-    if (live) {
+    if (live && (p.passes & 1u)) {
         for (uint32_t b = slot; b < p.nb; b += kSolveSlots) {   // PrePhysicsPosing's reset, poser_impl.inl:366-377
             st.set_quat(b, kStTotalRot, q_identity());
             st.set_quat(b, kStIkRot, q_identity());
@@ -637,6 +637,7 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordere
     __syncthreads();
     float4 *out = reinterpret_cast<float4 *>(p.out) + size_t(live ? inst : 0) * p.nb * 4;
     for (uint32_t pass = 0; pass < 2; ++pass) {
+        if (!(p.passes >> pass & 1u)) continue;              // the physics seam runs the two lists as two launches
         const uint32_t r0 = pass ? p.n_rounds_pre : 0, r1 = pass ? p.n_rounds : p.n_rounds_pre;
         for (uint32_t r = r0; r < r1; ++r) {
             const RoundRec rr = p.rounds[r];
@@ -667,7 +668,125 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordere
     }
 }
 
+// Matrix4x4<T>::Inverse(), L/util/math_impl.inl:822-897: Gauss-Jordan on [M | I] with scaled partial pivoting (a zero
+// row or a zero last pivot gives the ZERO matrix), forward elimination, then the upper triangle is cleared column by
+// column and every row divided by its pivot -- the reference's operations in the reference's order (f32 division is
+// correctly rounded in HIP).  The reference swaps row pointers; here the two rows are exchanged by value, with every
+// index a compile-time constant so that the 4x8 work matrix stays in registers.
+__device__ Mat4 inverse(const Mat4 &in) {
+    float s[4][8], scale[4];
+    Mat4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[i][j] = in.m[i][j]; s[i][j + 4] = i == j ? 1.f : 0.f; out.m[i][j] = 0.f; }
+    bool zero = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        scale[i] = fabsf(s[i][0]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) { const float x = fabsf(s[i][j]); if (x > scale[i]) scale[i] = x; }
+        zero = zero || scale[i] == 0.f;
+    }
+    if (zero) return out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int pivot = i;
+        float best = fabsf(s[i][i] / scale[i]);
+#pragma unroll
+        for (int q = i + 1; q < 4; ++q) {
+            const float x = fabsf(s[q][i] / scale[q]);
+            if (x > best) { best = x; pivot = q; }
+        }
+#pragma unroll
+        for (int q = i + 1; q < 4; ++q) {
+            if (pivot == q) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const float t = s[i][c]; s[i][c] = s[q][c]; s[q][c] = t; }
+                const float t = scale[i]; scale[i] = scale[q]; scale[q] = t;
+            }
+        }
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            const float m = s[j][i] / s[i][i];
+            s[j][i] = 0.f;
+#pragma unroll
+            for (int jj = i + 1; jj < 8; ++jj) s[j][jj] = s[j][jj] - m * s[i][jj];
+        }
+    }
+    if (s[3][3] == 0.f) return out;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            const float m = s[j][i] / s[i][i];
+#pragma unroll
+            for (int jj = j + 1; jj < 8; ++jj) s[j][jj] = s[j][jj] - m * s[i][jj];
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out.m[i][j] = s[i][j + 4] / s[i][i];
+    return out;
+}
+
+// BulletPhysicsReactor::React's writes into the poser (mmd-bullet_impl.inl:312-326), one thread per instance:
+// Synchronize (:34-40) for every listed bone -- the body's transform becomes the bone's skinning matrix -- then, in
+// list order, Fix (:42-56) for the strict ones:
+//     local = global_offset_inv * skinning;  with a parent: local = local * inverse(parent_local)
+//     local.row3.xyz = total_translation + local_offset;  with a parent: local = local * parent_local
+//     skinning = global_offset * local
+// (parent_local is read once, as it stands when the bone's turn comes -- a parent fixed earlier in the list shows its
+// new matrix, one fixed later its old one).
+__global__ __launch_bounds__(kBoneMorphThreads) void physics_override_kernel(const PhysicsParams p) {
+    const uint32_t inst = blockIdx.x * kBoneMorphThreads + threadIdx.x;
+    if (inst >= p.ni) return;
+    const State st = {p.state + inst, p.ni};
+    float4 *out = reinterpret_cast<float4 *>(p.out) + size_t(inst) * p.nb * 4;
+    const float4 *in = reinterpret_cast<const float4 *>(p.skinning) + size_t(inst) * p.k * 4;
+    for (uint32_t k = 0; k < p.k; ++k) {
+        const uint32_t b = p.bone[k];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) out[4 * size_t(b) + y] = in[4 * size_t(k) + y];
+    }
+    for (uint32_t k = 0; k < p.k; ++k) {
+        if (!p.strict[k]) continue;
+        const uint32_t b = p.bone[k];
+        const BoneRec rec = p.bones[b];
+        Mat4 S, G;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const float4 r = out[4 * size_t(b) + y];
+            S.m[y][0] = r.x; S.m[y][1] = r.y; S.m[y][2] = r.z; S.m[y][3] = r.w;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) G.m[y][x] = x == y ? 1.f : 0.f;
+        }
+        G.m[3][0] = -rec.neg_rest[0]; G.m[3][1] = -rec.neg_rest[1]; G.m[3][2] = -rec.neg_rest[2];
+        Mat4 L = mul(G, S), PL;
+        if (rec.parent >= 0) {
+            PL = st.local(uint32_t(rec.parent));
+            L = mul(L, inverse(PL));
+        }
+        L.m[3][0] = st.at(b, kStTotalTr + 0) + rec.local_offset[0];
+        L.m[3][1] = st.at(b, kStTotalTr + 1) + rec.local_offset[1];
+        L.m[3][2] = st.at(b, kStTotalTr + 2) + rec.local_offset[2];
+        if (rec.parent >= 0) L = mul(L, PL);
+        st.set_local(b, L);
+        G.m[3][0] = rec.neg_rest[0]; G.m[3][1] = rec.neg_rest[1]; G.m[3][2] = rec.neg_rest[2];
+        S = mul(G, L);
+#pragma unroll
+        for (int y = 0; y < 4; ++y) out[4 * size_t(b) + y] = make_float4(S.m[y][0], S.m[y][1], S.m[y][2], S.m[y][3]);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_physics_override(const PhysicsParams &p, hipStream_t stream) {
+    if (p.ni == 0 || p.k == 0) return hipSuccess;
+    hipLaunchKernelGGL(physics_override_kernel, dim3((p.ni + kBoneMorphThreads - 1) / kBoneMorphThreads),
+                       dim3(kBoneMorphThreads), 0, stream, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_bone_track_eval(const BoneTrackParams &p, hipStream_t stream) {
     const size_t n = size_t(p.ni) * p.nb;

@@ -11,6 +11,7 @@ hipError_t launch_bone_track_eval(const BoneTrackParams &p, hipStream_t stream);
 hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream);
 hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream);
 hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream);
+hipError_t launch_physics_override(const PhysicsParams &p, hipStream_t stream);
 
 // api.cpp: the device and stream a motion / rig call runs on -- the model's own when a (device) model
 // is given, so that the deform call that follows is ordered after it; else the selected device's

@@ -207,7 +207,7 @@ class SkeletonDesc(C.Structure):
                 ("ik_target", C.c_void_p), ("ik_loop_count", C.c_void_p), ("ik_angle_limit", C.c_void_p),
                 ("ik_link_offset", C.c_void_p), ("ik_link_bone", C.c_void_p), ("ik_link_limited", C.c_void_p),
                 ("ik_link_lo", C.c_void_p), ("ik_link_hi", C.c_void_p),
-                ("n_morphs", C.c_uint32), ("reserved0", C.c_uint32), ("morph_type", C.c_void_p),
+                ("n_morphs", C.c_uint32), ("create_flags", C.c_uint32), ("morph_type", C.c_void_p),
                 ("morph_offset", C.c_void_p), ("morph_index", C.c_void_p), ("morph_value", C.c_void_p),
                 ("morph_rotation", C.c_void_p)]
 
@@ -220,6 +220,13 @@ class SkeletonInfo(C.Structure):
 
 
 SOLVER_PARALLEL_FK, SOLVER_SERIAL = 0, 1
+SKELETON_PHYSICS_SEAM = 1
+OVERRIDES_ON_DEVICE = 1 << 5
+
+
+class PhysicsOverrides(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_bones", C.c_uint32), ("bone", C.c_void_p), ("strict", C.c_void_p),
+                ("skinning", C.c_void_p)]
 
 
 class Skeleton:
@@ -229,7 +236,7 @@ class Skeleton:
     synth.make_ik_rig / the PMX loader; None for a rig without IK."""
 
     def __init__(self, rest_position, parent, transform_level=None, flags=None, append_parent=None,
-                 append_ratio=None, ik=None, morphs=None):
+                 append_ratio=None, ik=None, morphs=None, physics_seam=False):
         """morphs = dict(type i32[NM], offset u32[NM+1], index u32[E], value f32[E,3], rotation f32[E,4] or None):
         the model's morph table; its group and bone morphs feed mmdx_skeleton_solve_morphed."""
         rest = np.ascontiguousarray(rest_position, np.float32).reshape(-1, 3)
@@ -256,7 +263,8 @@ class Skeleton:
         else:
             mk = [None] * 5
         ptr = lambda a: a.ctypes.data if a is not None else None          # noqa: E731
-        d = SkeletonDesc(C.sizeof(SkeletonDesc), nb, *[ptr(a) for a in keep], nm, 0, *[ptr(a) for a in mk])
+        d = SkeletonDesc(C.sizeof(SkeletonDesc), nb, *[ptr(a) for a in keep], nm, SKELETON_PHYSICS_SEAM if physics_seam else 0,
+                         *[ptr(a) for a in mk])
         self._keep = keep + mk
         self.nm = nm
         self.h = C.c_void_p()
@@ -282,6 +290,38 @@ class Skeleton:
             api.check(api.lib().mmdx_skeleton_solve_morphed(self.h, model.h if model is not None else None, p.shape[0],
                                                             p.ctypes.data, w.ctypes.data, flags, out.ctypes.data))
         return out
+
+    # -- the physics seam: PrePhysicsPosing | the reactor's writes | PostPhysicsPosing (main.cpp:1801-1810) ------------
+    def solve_pre(self, poses, model=None, morph_weights=None) -> np.ndarray:
+        """Reset + bone morphs + the pre-physics bone list -> palettes [NI, NB, 16] (rows of post-physics bones are
+        unspecified until solve_post)."""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, self.nb, POSE_FLOATS)
+        self._seam_out = np.empty((p.shape[0], self.nb, 16), np.float32)
+        w, flags = None, 0
+        if morph_weights is not None:
+            w = np.ascontiguousarray(morph_weights, np.float32)
+            flags = api.WEIGHTS_SHARED if w.ndim == 1 else 0
+        api.check(api.lib().mmdx_skeleton_solve_pre(self.h, model.h if model is not None else None, p.shape[0],
+                                                    p.ctypes.data, w.ctypes.data if w is not None else None, flags,
+                                                    self._seam_out.ctypes.data))
+        return self._seam_out.copy()
+
+    def solve_post(self, bones, strict, skinning, model=None) -> np.ndarray:
+        """The reactor's writes (skinning [NI, K, 16] for bones [K]; Fix where strict [K]) then the post-physics list
+        -> the complete palettes [NI, NB, 16]."""
+        b = np.ascontiguousarray(bones, np.int32).reshape(-1)
+        k = b.size
+        st = np.ascontiguousarray(strict, np.uint8).reshape(k)
+        xf = np.ascontiguousarray(skinning, np.float32)
+        xf = xf.reshape(-1, k, 16) if k else xf.reshape(xf.shape[0], 0, 16)
+        ni = xf.shape[0]
+        if getattr(self, "_seam_out", None) is None or self._seam_out.shape[0] != ni:
+            self._seam_out = np.empty((ni, self.nb, 16), np.float32)     # the library rejects the call
+        ov = PhysicsOverrides(C.sizeof(PhysicsOverrides), k, b.ctypes.data if k else None, st.ctypes.data if k else None,
+                              xf.ctypes.data if k else None)
+        api.check(api.lib().mmdx_skeleton_solve_post(self.h, model.h if model is not None else None, ni, C.byref(ov), 0,
+                                                     self._seam_out.ctypes.data))
+        return self._seam_out.copy()
 
     def solve_device(self, n_instances: int, poses_ptr, out_ptr, model=None, weights_ptr=None, shared=False) -> None:
         """poses, palettes (and morph rates) resident in HBM; asynchronous on the model's stream."""
