@@ -467,7 +467,10 @@ enum {
 };
 
 /* Index validation happens here (MMDX_ERR_BAD_INDEX), so solve cannot read out of range.
- * MMDX_ERR_UNSUPPORTED: an IK link or target that is itself an IK bone (the reference would recurse). */
+ * Nested IK -- a link or target that is itself an IK bone -- is solved the way the reference's recursion does
+ * (UpdateBoneTransform re-enters itself for links and target, L/motion/poser_impl.inl:196-206), up to 3 solves
+ * deep.  MMDX_ERR_UNSUPPORTED: deeper nesting, or an IK bone that is (indirectly) part of its own solve (endless
+ * recursion in the reference). */
 MMDX_API mmdx_status mmdx_skeleton_create(const mmdx_skeleton_desc *desc, mmdx_skeleton_t *out_skeleton);
 MMDX_API mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t skeleton, mmdx_skeleton_info *info);
 /* out_palettes[i][b][16] from poses[i][b][MMDX_POSE_FLOATS].  flags: MMDX_POSES_ON_DEVICE |

@@ -692,8 +692,7 @@ static void apply_bone_morph(const bmorph_ctx *c, uint32_t m, float rate) {
 /* Everything as flat arrays (NULL allowed where no bone uses it): append_parent / append_ratio [NB];
  * ik_target [NB], ik_loop [NB], ik_angle [NB], ik_link_off [NB+1], ik_link_bone / ik_link_limited [L],
  * ik_link_lo / ik_link_hi [L][3]; morph table (nm, type, off, index, value[E][3], rotation[E][4] or NULL) with
- * rates[nm] or nm == 0.  scratch = NB * (sizeof(bone_state_t) + 5) bytes.  Returns -1 when an IK link or
- * target is itself an IK bone (recursive solves are not restated) or an index is out of range. */
+ * rates[nm] or nm == 0.  scratch = NB * (sizeof(bone_state_t) + 5) bytes.  Returns -1 when an index is out of range. */
 /* Matrix4x4<T>::Inverse(), L/util/math_impl.inl:822-897: Gauss-Jordan on [M | I] with scaled partial pivoting
  * (row i's scale = its largest |element|; a zero row or a zero last pivot gives the ZERO matrix), forward
  * elimination, then the upper triangle is cleared column by column and every row divided by its pivot. */
@@ -822,9 +821,11 @@ static int bone_solve_impl(uint32_t nb, const float *rest, const int64_t *parent
     memset(is_link, 0, nb);
     for (uint32_t b = 0; b < nb; ++b) {
         if (!(flags && (flags[b] & 0x0020))) continue;
-        if (ik_target[b] < 0 || (uint64_t)ik_target[b] >= nb || (flags[ik_target[b]] & 0x0020)) return -1;
+        /* a link or target that is itself an IK bone is legal: update_bone recurses like UpdateBoneTransform does
+         * (poser_impl.inl:196-206); cycles (endless recursion upstream) are the caller's to avoid */
+        if (ik_target[b] < 0 || (uint64_t)ik_target[b] >= nb) return -1;
         for (uint32_t l = ik_link_off[b]; l < ik_link_off[b + 1]; ++l) {
-            if (ik_link_bone[l] < 0 || (uint64_t)ik_link_bone[l] >= nb || (flags[ik_link_bone[l]] & 0x0020)) return -1;
+            if (ik_link_bone[l] < 0 || (uint64_t)ik_link_bone[l] >= nb) return -1;
             is_link[ik_link_bone[l]] = 1;
         }
     }

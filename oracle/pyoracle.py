@@ -166,7 +166,7 @@ class Oracle:
             _p(r, C.c_float) if r is not None else None,
             _p(poses, C.c_float), _p(out, C.c_float), scratch.ctypes.data_as(C.c_void_p))
         if rc != 0:
-            raise ValueError("oracle bone solve: nested IK or an index out of range")
+            raise ValueError("oracle bone solve: an index out of range")
         return out
 
     def bone_solve_physics(self, rest, parent, poses, over_bone, over_strict, over_skin, level=None, flags=None,
@@ -202,7 +202,7 @@ class Oracle:
             _p(poses, C.c_float), _p(out, C.c_float), scratch.ctypes.data_as(C.c_void_p),
             C.c_uint32(k), _p(ob, C.c_int64), _p(os_, C.c_uint8), _p(ok, C.c_float), _p(pre, C.c_float))
         if rc != 0:
-            raise ValueError("oracle bone solve: nested IK or an index out of range")
+            raise ValueError("oracle bone solve: an index out of range")
         return out, pre
 
     def matrix_inverse(self, m):

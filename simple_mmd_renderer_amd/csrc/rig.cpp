@@ -102,12 +102,17 @@ void solve_event_sets(const SkeletonPlan &plan, uint32_t bone, std::vector<uint3
         if (r.bits & (kBoneAppendRot | kBoneAppendTr)) reads.push_back(uint32_t(r.append_parent));
         writes.push_back(x);
     };
-    transform(bone);
-    if (plan.bones[bone].bits & kBoneHasIk) {                 // the CCD loop re-transforms its links and target
-        const IkRec &ik = plan.iks[plan.bones[bone].ik];
-        for (uint32_t j = 0; j < ik.nlinks; ++j) transform(plan.links[ik.link0 + j].bone);
-        transform(ik.target);
-    }
+    // UpdateBoneTransform of `x`: its transform and, for an IK bone, the CCD loop, which re-transforms its links and
+    // target -- recursively where one of those is itself an IK bone (build_skeleton bounds the depth, no cycles)
+    std::function<void(uint32_t)> update = [&](uint32_t x) {
+        transform(x);
+        if (plan.bones[x].bits & kBoneHasIk) {
+            const IkRec &ik = plan.iks[plan.bones[x].ik];
+            for (uint32_t j = 0; j < ik.nlinks; ++j) update(plan.links[ik.link0 + j].bone);
+            update(ik.target);
+        }
+    };
+    update(bone);
 }
 
 namespace {
@@ -342,7 +347,6 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
             return bad(MMDX_ERR_INVALID_ARGUMENT, "ik_link_offset is not ascending or the link arrays are NULL");
         const int32_t tgt = d.ik_target[b];
         if (tgt < 0 || uint32_t(tgt) >= nb) return bad(MMDX_ERR_BAD_INDEX, "IK target of bone " + std::to_string(b) + " is out of range");
-        if (flag(uint32_t(tgt)) & MMDX_BONE_HAS_IK) return bad(MMDX_ERR_UNSUPPORTED, "IK target of bone " + std::to_string(b) + " is itself an IK bone");
         IkRec ik = IkRec();
         ik.target = uint32_t(tgt);
         const int32_t loop = d.ik_loop_count[b];
@@ -353,7 +357,6 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
         for (uint32_t l = l0; l < l1; ++l) {
             const int32_t lb = d.ik_link_bone[l];
             if (lb < 0 || uint32_t(lb) >= nb) return bad(MMDX_ERR_BAD_INDEX, "IK link of bone " + std::to_string(b) + " is out of range");
-            if (flag(uint32_t(lb)) & MMDX_BONE_HAS_IK) return bad(MMDX_ERR_UNSUPPORTED, "IK link of bone " + std::to_string(b) + " is itself an IK bone");
             LinkRec lr = LinkRec();
             lr.bone = uint32_t(lb);
             lr.limited = d.ik_link_limited[l] ? 1u : 0u;
@@ -379,14 +382,46 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
         out.bones[b].ik = uint32_t(out.iks.size());
         out.iks.push_back(ik);
     }
+    // Nested IK: a link or target that is itself an IK bone is solved inside the outer solve, as the reference's
+    // recursion does (UpdateBoneTransform calls itself for links and target, poser_impl.inl:196-206).  The device code
+    // unrolls that recursion kMaxIkDepth deep; a cycle (endless recursion upstream) or a deeper nest is rejected.
+    {
+        std::vector<uint32_t> depth(nb, 0);                 // 0 = not computed
+        std::vector<uint8_t> on_path(nb, 0);
+        std::function<int64_t(uint32_t)> nest = [&](uint32_t x) -> int64_t {
+            if (!(out.bones[x].bits & kBoneHasIk)) return 0;
+            if (on_path[x]) return -1;
+            if (depth[x]) return depth[x];
+            on_path[x] = 1;
+            IkRec &ik = out.iks[out.bones[x].ik];
+            int64_t deepest = 0;
+            for (uint32_t j = 0; j <= ik.nlinks; ++j) {
+                const uint32_t y = j < ik.nlinks ? out.links[ik.link0 + j].bone : ik.target;
+                const int64_t dd = nest(y);
+                if (dd < 0) return -1;
+                if (dd > 0) ik.nested = 1;
+                deepest = std::max(deepest, dd);
+            }
+            on_path[x] = 0;
+            depth[x] = uint32_t(deepest + 1);
+            return depth[x];
+        };
+        for (uint32_t b = 0; b < nb; ++b) {
+            const int64_t dd = nest(b);
+            if (dd < 0) return bad(MMDX_ERR_UNSUPPORTED, "IK bone " + std::to_string(b) + " is (indirectly) a link or target of its own "
+                                                         "solve: the reference recurses without end");
+            if (dd > int64_t(kMaxIkDepth))
+                return bad(MMDX_ERR_UNSUPPORTED, "IK solves nested more than " + std::to_string(kMaxIkDepth) + " deep at bone " + std::to_string(b));
+        }
+    }
     // Which chains can run on the LDS window: link j's parent is link j+1, the target hangs off link 0,
-    // all bones distinct, no append bone inside (appends read bones outside the window).
+    // all bones distinct, no append bone inside (appends read bones outside the window), no nested IK.
     for (uint32_t b = 0; b < nb; ++b) {
         if (!(out.bones[b].bits & kBoneHasIk)) continue;
         IkRec &ik = out.iks[out.bones[b].ik];
         const LinkRec *lk = out.links.data() + ik.link0;
         const uint32_t n = ik.nlinks;
-        bool ok = n >= 1 && n <= kMaxFastLinks && ik.target != b && out.bones[ik.target].parent == int32_t(lk[0].bone) &&
+        bool ok = !ik.nested && n >= 1 && n <= kMaxFastLinks && ik.target != b && out.bones[ik.target].parent == int32_t(lk[0].bone) &&
                   !(out.bones[ik.target].bits & (kBoneAppendRot | kBoneAppendTr));
         for (uint32_t j = 0; ok && j < n; ++j) {
             if (out.bones[lk[j].bone].bits & (kBoneAppendRot | kBoneAppendTr)) ok = false;

@@ -64,8 +64,9 @@ struct IkRec {
     float angle_limit;
     uint32_t fast;                              // plain chain topology: solved on an LDS window
     int32_t outside_parent;                     // fast: parent bone of the root-most link, -1 = none
-    uint32_t pad;
+    uint32_t nested;                            // a link or the target is itself an IK bone: its solve runs inside this one
 };
+constexpr uint32_t kMaxIkDepth = 3;             // IK solves nested inside one another (the reference recurses without bound)
 constexpr uint32_t kMaxFastLinks = 6;           // window = (links + target + outside parent) x 31 floats per lane
 struct LinkRec {                                // the per-link constants the Poser ctor derives (48 B)
     uint32_t bone, limited, order, fix;

@@ -8,6 +8,8 @@
 #include "rig.hpp"
 #include "rig_kernels.hpp"
 
+#include <type_traits>
+
 namespace mmdx {
 namespace {
 
@@ -446,9 +448,22 @@ struct WindowChain {
 
 // The CCD loop of UpdateBoneTransform, poser_impl.inl:196-309, over a state `st` in which the chain `ch` says
 // where link j and its parent live, the target at tidx, its parent at tpar (< 0 = none).
-template <class S, class Chain>
+// Nested IK (`nested` != 0, HBM state only): a link or the target that is itself an IK bone gets its own solve right
+// after it has been transformed, exactly where UpdateBoneTransform would recurse -- for the links once, when the outer
+// solve places them, for the target every time the loop re-places it.  DEPTH counts the solves on the stack; rig.cpp
+// rejects rigs that would exceed kMaxIkDepth.
+template <int DEPTH>
+__device__ __noinline__ void solve_ik_nested(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst, uint32_t b);
+
+template <class S, class Chain, int DEPTH = 1>
 __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint32_t inst, const IkRec &ik,
                     const LinkRec *links, const V3 ik_pos, const Chain &ch, uint32_t tidx, int32_t tpar) {
+    constexpr bool kCanNest = std::is_same<S, State>::value && DEPTH < int(kMaxIkDepth);
+    auto inner = [&](uint32_t bone, uint32_t bits) {
+        if constexpr (kCanNest) {
+            if (ik.nested && (bits & kBoneHasIk)) solve_ik_nested<DEPTH + 1>(st, p, pose, inst, bone);
+        }
+    };
     const BoneRec trec = p.bones[ik.target];
     const float4 tt = pose[2 * size_t(ik.target)], tr = pose[2 * size_t(ik.target) + 1];
     const MorphXf tmx = morph_of(p, ik.target, inst);
@@ -458,8 +473,10 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
         const BoneRec rec = p.bones[lb];
         transform_at(st, rec, morph_of(p, lb, inst), pose[2 * size_t(lb)], pose[2 * size_t(lb) + 1], ch.idx(j), ch.par(j),
                      uint32_t(rec.append_parent));
+        inner(lb, rec.bits);
     }
     transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
+    inner(ik.target, trec.bits);
     V3 tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
     V3 err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
     if (v_dot(err, err) < 1e-7f) return;
@@ -526,11 +543,20 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
                          bs, ch.par(jj));
             }
             transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
+            inner(ik.target, trec.bits);
             tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
         }
         err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
         if (v_dot(err, err) < 1e-7f) return;
     }
+}
+
+template <int DEPTH>
+__device__ __noinline__ void solve_ik_nested(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst, uint32_t b) {
+    const IkRec ik = p.iks[p.bones[b].ik];
+    const LinkRec *links = p.links + ik.link0;
+    const V3 ik_pos = {st.at(b, kStLocal + 12), st.at(b, kStLocal + 13), st.at(b, kStLocal + 14)};
+    ccd<State, TableChain, DEPTH>(st, p, pose, inst, ik, links, ik_pos, TableChain{p, links}, ik.target, p.bones[ik.target].parent);
 }
 
 // One IK bone.  Chains with the usual topology (every link's parent is the next link, the target hangs off

@@ -361,6 +361,38 @@ def make_ik_rig(nb: int, seed: int, n_ik: int = 4, n_append: int = 4, post_physi
     return rest, parent, level, flags, append_parent, append_ratio, ik
 
 
+def make_nested_ik_rig(nb: int, seed: int, n_ik: int = 4, n_append: int = 3):
+    """make_ik_rig with NESTED IK added (the reference's UpdateBoneTransform recurses into a link or target that is
+    itself an IK bone, poser_impl.inl:196-206): IK bone A gets IK bone B as an extra, root-most link (B's whole chain is
+    solved when A's solve places its links), and a new IK bone C takes IK bone B... as its TARGET (B's chain is solved
+    every time C's loop re-places its target).  Loop counts are kept small: the cost multiplies."""
+    rest, parent, level, flags, ap, ar, ik = make_ik_rig(nb, seed, n_ik=n_ik, n_append=n_append, post_physics=0.0, levels=1)
+    rng = np.random.RandomState(seed + 7000)
+    iks = [b for b in range(nb) if flags[b] & 0x0020]
+    assert len(iks) >= 3
+    a_, b_, c_ = iks[0], iks[1], iks[2]
+    loop = ik["loop"].copy()
+    loop[iks] = [int(rng.choice([2, 3, 5])) for _ in iks]
+    loop[b_] = 4
+    links = {b: list(ik["link_bone"][ik["link_off"][b]:ik["link_off"][b + 1]]) for b in range(nb)}
+    lim = {b: list(ik["link_limited"][ik["link_off"][b]:ik["link_off"][b + 1]]) for b in range(nb)}
+    lo = {b: [x for x in ik["link_lo"][ik["link_off"][b]:ik["link_off"][b + 1]]] for b in range(nb)}
+    hi = {b: [x for x in ik["link_hi"][ik["link_off"][b]:ik["link_off"][b + 1]]] for b in range(nb)}
+    # (1) B becomes a link of A
+    links[a_].append(b_); lim[a_].append(0); lo[a_].append(np.zeros(3, np.float32)); hi[a_].append(np.zeros(3, np.float32))
+    # (2) C's target becomes IK bone B; C keeps its links
+    target = ik["target"].copy()
+    target[c_] = b_
+    link_off, link_bone, link_limited, llo, lhi = [0], [], [], [], []
+    for b in range(nb):
+        link_bone += links[b]; link_limited += lim[b]; llo += lo[b]; lhi += hi[b]
+        link_off.append(len(link_bone))
+    ik2 = dict(target=target, loop=loop, angle=ik["angle"], link_off=np.asarray(link_off, np.uint32),
+               link_bone=np.asarray(link_bone, np.int32).reshape(-1), link_limited=np.asarray(link_limited, np.uint8).reshape(-1),
+               link_lo=np.asarray(llo, np.float32).reshape(-1, 3), link_hi=np.asarray(lhi, np.float32).reshape(-1, 3))
+    return rest, parent, level, flags, ap, ar, ik2
+
+
 def make_bone_morphs(nb: int, seed: int, n_bone: int = 5, n_group: int = 3, n_other: int = 2):
     """A morph table with bone morphs (translation + rotation, several bones each, a bone hit by several morphs),
     group morphs over them (depth 2, a bone morph reached directly and through a group) and a few vertex / uv
