@@ -762,3 +762,4 @@ def test_vmd_to_crowd_end_to_end(oracle):
         for b in (d_fr, d_pal, d_w, d_a, d_b):
             b.free()
     mm.close()
+
