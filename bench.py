@@ -444,6 +444,38 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
                                            "vertices_per_s": nfr * model3.nv / (ms64 * 1e-3),
                                            "algorithmic_GBs": b64 / (ms64 * 1e-3) / 1e9,
                                            "frac_of_8TBs": b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # the same single-frame call recorded into a HIP graph, 64 frames per replay (host cost per frame: one launch per
+    # 64 frames instead of 64; the device-side time per frame is the kernel's either way)
+    try:
+        import time as _t
+        dm3.sync()
+        dm3.graph_begin()
+        for f in range(nfr):
+            dm3.deform_batched_raw(1, d_w.ptr + f * model3.nm * 4, d_pal.ptr + f * model3.nb * 64,
+                                   d_a.ptr + f * model3.nv * 12, d_b.ptr + f * model3.nv * 12, api.OUT_SOA, flags_dev)
+        g = dm3.graph_end()
+
+        def eager64():
+            for f in range(nfr):
+                dm3.deform_batched_raw(1, d_w.ptr + f * model3.nm * 4, d_pal.ptr + f * model3.nb * 64,
+                                       d_a.ptr + f * model3.nv * 12, d_b.ptr + f * model3.nv * 12, api.OUT_SOA, flags_dev)
+        ms_g = time_calls(dm3, g.launch, 20) / nfr
+        ms_e = time_calls(dm3, eager64, 20) / nfr
+
+        def wall(fn, n=50):
+            dm3.sync()
+            t0 = _t.perf_counter()
+            for _ in range(n):
+                fn()
+            host = (_t.perf_counter() - t0) / n
+            dm3.sync()
+            return host
+        out["config2_single_frame"].update({"graph_replay_ms_per_frame": ms_g, "eager_ms_per_frame_64_in_a_row": ms_e,
+                                            "host_us_per_frame_graph": wall(g.launch) / nfr * 1e6,
+                                            "host_us_per_frame_eager": wall(eager64) / nfr * 1e6})
+        g.close()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["config2_single_frame"]["graph_error"] = repr(e)
     for b in (d_pal, d_w, d_a, d_b):
         b.free()
     cpu_reference_frame(out["config2_single_frame"], model3, rates, pals)

@@ -183,6 +183,22 @@ MMDX_API mmdx_status mmdx_model_slot_weights(mmdx_model_t model, const float *mo
 /* Borrow an external HIP stream (hipStream_t) instead of the handle's own; NULL restores it. */
 MMDX_API mmdx_status mmdx_model_set_stream(mmdx_model_t model, void *hip_stream);
 
+/* ---- HIP-graph replay of a frame's device work ------------------------------------------------------
+ * Between mmdx_graph_begin and mmdx_graph_end everything the library enqueues on `model`'s stream is RECORDED instead
+ * of executed: mmdx_deform_batched, mmdx_morph_motion_eval, mmdx_bone_motion_eval and mmdx_skeleton_solve* called with
+ * this model and every operand in device memory (MMDX_*_ON_DEVICE).  mmdx_graph_launch then replays the whole sequence
+ * with ONE submission (asynchronous, on the model's stream); the recorded calls read and write the same device
+ * addresses on every replay, so a frame is "update the inputs in place, launch".  What it buys is host time: a
+ * frame of motion -> poses -> palettes -> vertices is four to six launches (~4 us of host time each); the device-side
+ * gaps between dependent kernels are the same either way.  Rules: run the same sequence once un-captured first (it
+ * sizes the handles' scratch buffers; a call that would have to allocate while recording fails), no host operands,
+ * no mmdx_profile_enable while recording, one recording per model at a time. */
+typedef struct mmdx_graph_s *mmdx_graph_t;
+MMDX_API mmdx_status mmdx_graph_begin(mmdx_model_t model);
+MMDX_API mmdx_status mmdx_graph_end(mmdx_model_t model, mmdx_graph_t *out_graph);
+MMDX_API mmdx_status mmdx_graph_launch(mmdx_graph_t graph);
+MMDX_API void mmdx_graph_destroy(mmdx_graph_t graph);
+
 /* ---- the hot path ---------------------------------------------------------------------------- */
 /* deform(model, morph_weights, bone_palette, out_verts): one instance, host pointers, synchronous.
  * out_pos/out_nrm = f32[NV][3] each = Poser::pose_image after Poser::Deform(). */

@@ -128,6 +128,10 @@ SIGNATURES = {
                                             C.c_void_p]),
     "mmdx_skeleton_solve_post": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mmdx_skeleton_destroy": (None, [C.c_void_p]),
+    "mmdx_graph_begin": (C.c_int32, [C.c_void_p]),
+    "mmdx_graph_end": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mmdx_graph_launch": (C.c_int32, [C.c_void_p]),
+    "mmdx_graph_destroy": (None, [C.c_void_p]),
     "mmdx_pmx_get_skeleton_desc": (C.c_int32, [C.c_void_p, C.c_void_p]),
 }
 

@@ -49,11 +49,14 @@ mmdx_status hip_fail(hipError_t e, const char *what) {
         if (e_ != hipSuccess) return hip_fail(e_, #expr);      \
     } while (0)
 
+thread_local bool tl_recording = false;   // a stream of this thread is recording a graph: nothing may allocate
+
 struct DevBuf {
     void *ptr = nullptr;
     size_t bytes = 0;
     hipError_t ensure(size_t need) {
         if (need <= bytes) return hipSuccess;
+        if (tl_recording) return hipErrorStreamCaptureUnsupported;   // run the sequence once un-captured first
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr; bytes = 0;
         hipError_t e = hipMalloc(&ptr, need);
@@ -97,10 +100,17 @@ struct mmdx_model_s {
     // per-call scratch (grown on demand, reused)
     DevBuf pal, rates, wslot, morphed, out_a, out_b;
     bool morphed_valid = false;     // `morphed` holds the result of a shared morph pass (MMDX_MORPH_UNCHANGED)
+    bool capturing = false;         // between mmdx_graph_begin and mmdx_graph_end: the stream records
     // page-locked bounce buffer for small outputs bound for pageable host memory (see mmdx_deform_batched)
     void *bounce = nullptr, *bounce_dev = nullptr;  // host address, device-side address
     size_t bounce_bytes = 0;
     void *bounce_in = nullptr;                     // the same for small pageable inputs (palette, rates)
+};
+
+struct mmdx_graph_s {
+    void *exec = nullptr;      // hipGraphExec_t
+    void *stream = nullptr;    // the model's stream at recording time
+    int device = 0;
 };
 
 namespace {
@@ -256,6 +266,7 @@ mmdx_status mmdx::resolve_stream(mmdx_model_t model, int *device, hipStream_t *s
     return MMDX_OK;
 }
 mmdx_status mmdx::hip_status(hipError_t e, const char *what) { return hip_fail(e, what); }
+bool mmdx::graph_recording() { return tl_recording; }
 
 // The wait at the end of a call that hands results back to the host.  A per-frame call is tens of
 // microseconds of device work; hipStreamSynchronize may put the thread to sleep and then pays a wake-up that is
@@ -438,6 +449,12 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (kind_a == PtrKind::Device || kind_b == PtrKind::Device)
             return fail(MMDX_ERR_INVALID_ARGUMENT, "out_a / out_b points to device memory: pass MMDX_OUT_ON_DEVICE");
         if (!host_direct_enabled()) map_a = map_b = nullptr;
+    }
+    if (m->capturing) {
+        const uint32_t need = MMDX_PALETTE_ON_DEVICE | MMDX_OUT_ON_DEVICE | (p.ns ? uint32_t(MMDX_WEIGHTS_ON_DEVICE) : 0u);
+        if ((a->flags & need) != need)
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory");
+        if (m->profile) return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_profile_enable and graph recording exclude each other");
     }
     const bool shared = (a->flags & MMDX_WEIGHTS_SHARED) != 0 || ni == 1;
     const uint64_t nvi = uint64_t(ni) * p.nv;
@@ -724,6 +741,8 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
                                    const uint32_t *frames, uint32_t flags, float *out_weights) {
     if (!mm || !frames || !out_weights || !n_instances)
         return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
+    if (tl_recording && (flags & (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE)) != (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory");
     const MorphMotionHost h = morph_motion_host(mm);
     MorphMotionDevice &d = morph_motion_device(mm);
     int n = 0;
@@ -733,6 +752,7 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = model && model->device >= 0 ? model->stream : nullptr;
     if (d.device != device) {
+        if (tl_recording) return fail(MMDX_ERR_INVALID_ARGUMENT, "first use of this motion on the device: run the sequence once before recording it");
         morph_motion_release_device(d);
         HIP_TRY(hipMalloc(&d.key_off, (size_t(h.nm) + 1) * 4));
         HIP_TRY(hipMalloc(&d.frames, std::max<size_t>(size_t(h.nkeys) * 4, 16)));
@@ -781,6 +801,52 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
         HIP_TRY(wait_stream(st));   // borrowed host frames must be consumed before returning
     }
     return MMDX_OK;
+}
+
+mmdx_status mmdx_graph_begin(mmdx_model_t m) {
+    if (!m || m->device < 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
+    if (m->capturing) return fail(MMDX_ERR_INVALID_ARGUMENT, "this model is already recording a graph");
+    if (m->profile) return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_profile_enable and graph recording exclude each other");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    m->capturing = true;
+    tl_recording = true;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_graph_end(mmdx_model_t m, mmdx_graph_t *out) {
+    if (!m || !out) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (!m->capturing) return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_graph_end without mmdx_graph_begin");
+    m->capturing = false;
+    tl_recording = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(m->stream, &g);
+    if (e != hipSuccess || !g) return hip_fail(e != hipSuccess ? e : hipErrorUnknown, "hipStreamEndCapture (a recorded call failed?)");
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+    mmdx_graph_s *gr = new (std::nothrow) mmdx_graph_s;
+    if (!gr) { (void)hipGraphExecDestroy(exec); return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    gr->exec = exec; gr->stream = m->stream; gr->device = m->device;
+    *out = gr;
+    return MMDX_OK;
+}
+
+mmdx_status mmdx_graph_launch(mmdx_graph_t g) {
+    if (!g) return fail(MMDX_ERR_INVALID_ARGUMENT, "graph is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(g->exec), static_cast<hipStream_t>(g->stream)));
+    return MMDX_OK;
+}
+
+void mmdx_graph_destroy(mmdx_graph_t g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g->exec));
+    delete g;
 }
 
 mmdx_status mmdx_device_malloc(void **ptr, size_t bytes) {

@@ -31,6 +31,7 @@ struct Buf {
     hipError_t ensure(size_t need) {
         need = std::max<size_t>(need, 16);
         if (need <= bytes) return hipSuccess;
+        if (graph_recording()) return hipErrorStreamCaptureUnsupported;   // run the sequence once un-captured first
         release();
         hipError_t e = hipMalloc(&ptr, need);
         if (e == hipSuccess) bytes = need;
@@ -113,6 +114,10 @@ mmdx_status mmdx_bone_motion_eval(mmdx_bone_motion_t m, mmdx_model_t model, uint
     hipStream_t st;
     if (mmdx_status s = resolve_stream(model, &device, &st)) return s;
     const BoneMotionHost &h = m->host;
+    if (graph_recording() && ((flags & (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE)) != (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE) ||
+                              m->device != device))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory and the "
+                                               "motion must have run on this device before");
     if (m->device != device) {
         for (Buf *b : {&m->key_off, &m->key_frame, &m->key_tr, &m->key_rot, &m->key_curve, &m->lut, &m->frames_in,
                        &m->out})
@@ -244,6 +249,14 @@ static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_
     hipStream_t st;
     if (mmdx_status r = resolve_stream(model, &device, &st)) return r;
     const SkeletonPlan &pl = s->plan;
+    if (graph_recording()) {
+        const uint32_t need = MMDX_OUT_ON_DEVICE | ((passes & 1u) ? uint32_t(MMDX_POSES_ON_DEVICE) : 0u) |
+                              ((passes & 1u) && morph_weights && !pl.apps.empty() ? uint32_t(MMDX_WEIGHTS_ON_DEVICE) : 0u);
+        if ((flags & need) != need || s->device != device || (ov && ov->n_bones))
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory, the "
+                                                   "skeleton must have run on this device before, and physics overrides "
+                                                   "(host lists) are not recordable");
+    }
     if (s->device != device) {
         s->release_all();
         HIP_TRY(s->apps.upload(pl.apps));

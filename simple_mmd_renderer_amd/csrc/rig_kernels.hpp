@@ -18,6 +18,8 @@ hipError_t launch_physics_override(const PhysicsParams &p, hipStream_t stream);
 // default stream.  Fails with MMDX_ERR_NO_DEVICE when there is no GPU (no CPU fallback).
 mmdx_status resolve_stream(mmdx_model_t model, int *device, hipStream_t *stream);
 mmdx_status hip_status(hipError_t e, const char *what);
+// api.cpp: the calling thread is between mmdx_graph_begin and mmdx_graph_end (nothing may allocate, copy from the host or wait)
+bool graph_recording();
 // api.cpp: host-visible completion of the work queued on `stream` (see there).
 hipError_t wait_stream(hipStream_t stream);
 

@@ -117,6 +117,27 @@ class PinnedArray:
             self.ptr = None
 
 
+class Graph:
+    """mmdx_graph_t: a recorded sequence of library calls on one model's stream, replayed with one submission."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def launch(self) -> None:
+        api.check(api.lib().mmdx_graph_launch(self.h))
+
+    def close(self) -> None:
+        if self.h:
+            api.lib().mmdx_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeformModel:
     """mmdx_model_t: the model compiled to the kernels' HBM layout, resident on one GPU."""
 
@@ -287,6 +308,15 @@ class DeformModel:
         ms = C.c_float(0)
         api.check(api.lib().mmdx_timer_stop(self.h, C.byref(ms)))
         return float(ms.value)
+
+    # -- HIP-graph replay of the device work of a frame ----------------------------------------------
+    def graph_begin(self) -> None:
+        api.check(api.lib().mmdx_graph_begin(self.h))
+
+    def graph_end(self) -> "Graph":
+        g = C.c_void_p()
+        api.check(api.lib().mmdx_graph_end(self.h, C.byref(g)))
+        return Graph(g)
 
     def profile_enable(self, on, every: int = 1) -> None:
         """Events around the morph kernels and the skinning kernel of every call, or of every `every`-th call."""
