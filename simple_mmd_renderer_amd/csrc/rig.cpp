@@ -399,7 +399,7 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
                 const uint32_t y = j < ik.nlinks ? out.links[ik.link0 + j].bone : ik.target;
                 const int64_t dd = nest(y);
                 if (dd < 0) return -1;
-                if (dd > 0) ik.nested = 1;
+                if (dd > 0) { ik.nested = 1; out.nested_ik = true; }
                 deepest = std::max(deepest, dd);
             }
             on_path[x] = 0;

@@ -112,6 +112,7 @@ struct SkeletonPlan {
     std::vector<uint32_t> events;               // bone ids, round after round
     std::vector<RoundRec> rounds;               // pre-physics rounds, then post-physics rounds
     uint32_t n_rounds_pre = 0, windows = 0;     // windows: LDS chain windows per instance
+    bool nested_ik = false;                     // some IK chain holds an IK bone among its links / as its target
 };
 
 // Bones whose state evaluating `bone` reads / writes in the ordered solver (UpdateBoneTransform incl. the IK
@@ -158,6 +159,7 @@ struct SerialParams {
     uint32_t fast_slots;                        // LDS window size in bones (0: no fast chain)
     uint32_t windows;                           // LDS windows per instance
     uint32_t passes;                            // bit 0: reset + pre-physics list, bit 1: post-physics list
+    uint32_t nested;                            // some IK chain holds an IK bone: the kernel variant with nested solves
 };
 
 // The physics reactor's writes between the two lists (mmdx_skeleton_solve_post): Synchronize, then Fix.

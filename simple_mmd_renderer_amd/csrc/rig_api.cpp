@@ -335,6 +335,7 @@ static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_
         sp.fast_slots = pl.fast_slots;
         sp.windows = pl.windows;
         sp.passes = passes;
+        sp.nested = pl.nested_ik ? 1u : 0u;
         bool borrowed_over = false;
         if ((passes & 2u) && ov && ov->n_bones) {     // the reactor's writes, between the two lists
             PhysicsParams pp;

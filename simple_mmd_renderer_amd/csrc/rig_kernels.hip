@@ -455,10 +455,11 @@ struct WindowChain {
 template <int DEPTH>
 __device__ __noinline__ void solve_ik_nested(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst, uint32_t b);
 
-template <class S, class Chain, int DEPTH = 1>
+template <class S, class Chain, int DEPTH = 0>
 __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint32_t inst, const IkRec &ik,
                     const LinkRec *links, const V3 ik_pos, const Chain &ch, uint32_t tidx, int32_t tpar) {
-    constexpr bool kCanNest = std::is_same<S, State>::value && DEPTH < int(kMaxIkDepth);
+    // DEPTH 0: the rig has no nested IK at all -- no call site, no stack, the register allocation of the plain solver
+    constexpr bool kCanNest = std::is_same<S, State>::value && DEPTH >= 1 && DEPTH < int(kMaxIkDepth);
     auto inner = [&](uint32_t bone, uint32_t bits) {
         if constexpr (kCanNest) {
             if (ik.nested && (bits & kBoneHasIk)) solve_ik_nested<DEPTH + 1>(st, p, pose, inst, bone);
@@ -565,6 +566,7 @@ __device__ __noinline__ void solve_ik_nested(const State &st, const SerialParams
 // latency instead of paying a round trip to the tables and the HBM scratch for every dependent access, and
 // the result is copied back.  Same arithmetic.  `lds_lane` = this lane's cell of the window's state,
 // `lds_consts` = the window's constants (the lanes of a window solve the same chain and write the same values).
+template <bool NESTED>
 __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *pose, uint32_t inst, uint32_t b,
                          __attribute__((address_space(3))) float *lds_lane,
                          __attribute__((address_space(3))) float *lds_consts) {
@@ -597,7 +599,8 @@ __device__ void solve_ik(const State &st, const SerialParams &p, const float4 *p
         for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, false);
         copy(n, ik.target, false);
     } else {
-        ccd(st, p, pose, inst, ik, links, ik_pos, TableChain{p, links}, ik.target, p.bones[ik.target].parent);
+        ccd<State, TableChain, NESTED ? 1 : 0>(st, p, pose, inst, ik, links, ik_pos, TableChain{p, links}, ik.target,
+                                               p.bones[ik.target].parent);
     }
 }
 
@@ -638,6 +641,9 @@ __global__ __launch_bounds__(kBoneMorphThreads) void bone_morph_kernel(const Bon
 // into rounds of events that touch disjoint bones (rig.cpp schedule_rounds), slot k of every instance runs
 // event k of the round, and a workgroup barrier separates the rounds.  Every event is the reference's
 // UpdateBoneTransform on the state the serial sequence would have shown it: same arithmetic, same result.
+// NESTED: the rig has an IK bone among some chain's links / targets (rig.cpp): the variant with the nested-solve call
+// sites (a stack, all 256 VGPRs); rigs without -- nearly all -- run the variant that has none.
+template <bool NESTED>
 __global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordered_kernel(const SerialParams p) {
     const uint32_t slot = threadIdx.x / kSolveInstances;
     const uint32_t inst = blockIdx.x * kSolveInstances + threadIdx.x % kSolveInstances;
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordere
             if (live && slot < rr.count) {
                 const uint32_t b = p.events[rr.first + slot];
                 transform_bone(st, p, pose, inst, b);
-                if (p.bones[b].bits & kBoneHasIk) solve_ik(st, p, pose, inst, b, lds_lane, lds_consts);
+                if (p.bones[b].bits & kBoneHasIk) solve_ik<NESTED>(st, p, pose, inst, b, lds_lane, lds_consts);
             }
             __syncthreads();
         }
@@ -841,12 +847,13 @@ hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream) {
     if (p.ni == 0 || p.nb == 0) return hipSuccess;
     const size_t lds = (size_t(window_floats(p.fast_slots)) * p.windows * kSolveInstances +
                         size_t(p.windows) * kMaxFastLinks * kLinkConstFloats) * sizeof(float);
+    auto kernel = p.nested ? skeleton_ordered_kernel<true> : skeleton_ordered_kernel<false>;
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skeleton_ordered_kernel),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(skeleton_ordered_kernel, dim3((p.ni + kSolveInstances - 1) / kSolveInstances),
+    hipLaunchKernelGGL(kernel, dim3((p.ni + kSolveInstances - 1) / kSolveInstances),
                        dim3(kSolveInstances * kSolveSlots), lds, stream, p);
     return hipGetLastError();
 }

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Collects the evidence bench.py's roofline cites: run on the GPU box from the repo root.
 #   bash tools/profile_round.sh rNN
-# 1. plain bench line; 2. rocprofv3 --kernel-trace --stats of the same command; 3./4. separate PMC
-# passes (FETCH_SIZE, WRITE_SIZE) as the microarchitecture guide prescribes; 5. a trace with the secondary
-# workloads on (all kernels of the library).  Outputs in gpurun_out/<tag>/.
+# 1. plain bench line; 2. rocprofv3 --kernel-trace --stats of the same command; 3./4. separate PMC passes (FETCH_SIZE,
+# WRITE_SIZE) as the microarchitecture guide prescribes; 5. SQ counter passes of the crowd step; 6. a trace with the
+# secondary workloads on (all kernels of the library); 7. the per-instance-morph workloads alone (trace + PMC passes);
+# 8. SQ counters of the rig kernels.  Outputs in gpurun_out/<tag>/; tools/summarize_profiles.py condenses them.
+# rocprofv3 is always given the program itself after "--" (python3 ...), never a wrapper.
 set -e -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -14,6 +16,24 @@ B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B > $out/bench_under_rocprof.json 2> $out/rocprof.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o fetch -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o write -- $B > /dev/null 2>&1
-# 5. every kernel of the library in one trace: the same run with the secondary workloads (bench extras) on
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_sq1 -o sq1 -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $out/pmc_sq2 -o sq2 -- $B > /dev/null 2>&1
+echo "crowd passes done" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_all -o all -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $out/rocprof_all.log
-find $out -name "*.csv" | sort
+echo "all-workloads trace done" >&2
+F="python3 tools/fused_bench.py c2 c5 c3p --iters 10"
+$F > $out/fused_plain.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/fused_kt -o kt -- $F > $out/fused_under_trace.txt 2> $out/fused_rocprof.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fused_fetch -o fetch -- $F > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/fused_write -o write -- $F > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/fused_sq1 -o sq1 -- $F > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $out/fused_sq2 -o sq2 -- $F > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $out/fused_tcc -o tcc -- $F > /dev/null 2>&1 || true
+echo "fused passes done" >&2
+R="python3 tools/rig_bench.py"
+$R > $out/rig_plain.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/rig_kt -o kt -- $R > /dev/null 2> $out/rig_rocprof.log
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --kernel-trace --output-format csv -d $out/rig_sq1 -o sq1 -- $R > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 --kernel-trace --output-format csv -d $out/rig_sq2 -o sq2 -- $R > /dev/null 2>&1 || true
+echo "rig passes done" >&2
+find $out -name "*.csv" | wc -l

@@ -14,6 +14,7 @@ committed under profiles/<round>/:  python tools/summarize_profiles.py gpurun_ou
                                   roofline.traffic when they do not match its own run)
 """
 import collections
+import re
 import csv
 import json
 import os
@@ -67,5 +68,44 @@ def main(src, dst):
         w.writerows(rows)
 
 
+def counter_summary(src, passes, dst_csv, want):
+    """Mean of every counter per kernel (name shortened) over the dispatches of separate --pmc passes."""
+    rows = []
+    for sub in passes:
+        path = [os.path.join(src, sub, f) for f in os.listdir(os.path.join(src, sub))] if os.path.isdir(os.path.join(src, sub)) else []
+        path = [q for q in path if q.endswith("counter_collection.csv")]
+        if not path:
+            continue
+        per = collections.OrderedDict()
+        with open(path[0], newline="") as f:
+            for r in csv.DictReader(f):
+                k = r["Kernel_Name"]
+                if not any(w in k for w in want):
+                    continue
+                mm = re.search(r"(\w+_kernel(?:<[^>]*>)?)", k)
+                key = (mm.group(1) if mm else k, r["Grid_Size"], r["Workgroup_Size"])
+                per.setdefault(key, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for (k, grid, wg), cs in per.items():
+            for c, v in cs.items():
+                rows.append((k, grid, wg, c, len(v), sum(v) / len(v), min(v), max(v)))
+    with open(dst_csv, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_threads", "workgroup", "counter", "dispatches", "mean", "min", "max"])
+        w.writerows(rows)
+
+
+def extras(src, dst):
+    """Round 2 additions: SQ counters of the crowd step, the per-instance-morph kernels (trace + PMC), the rig kernels."""
+    counter_summary(src, ["pmc_sq1", "pmc_sq2"], os.path.join(dst, "config3_pmc_sq.csv"), ["deform_kernel", "morph_apply"])
+    counter_summary(src, ["fused_fetch", "fused_write", "fused_sq1", "fused_sq2", "fused_tcc"],
+                    os.path.join(dst, "fused_gather_pmc.csv"), ["deform_kernel", "flatten"])
+    counter_summary(src, ["rig_sq1", "rig_sq2"], os.path.join(dst, "rig_pmc_sq.csv"), ["skeleton", "bone_track"])
+    for a, b in (("fused_kt/kt_kernel_stats.csv", "fused_gather_kernel_stats.csv"), ("fused_plain.txt", "fused_gather_bench.txt"),
+                 ("rig_kt/kt_kernel_stats.csv", "rig_kernel_stats.csv"), ("rig_plain.txt", "rig_bench.txt")):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+
+
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
+    extras(sys.argv[1], sys.argv[2])
