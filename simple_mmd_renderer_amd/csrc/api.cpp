@@ -182,10 +182,13 @@ int env_int(const char *name, int dflt) {
 // per-frame call has a budget of a few microseconds and getenv walks the whole environment.
 struct LaunchOverrides {
     int interleave, threads, lds_target, group, placement_log, placement_park;
+    int shared_fused;   // MMDX_SHARED_FUSED: crowds with a shared facial state gather the morphs inside the deform kernel: 0 never,
+                        // 1 up to 8 instances (default), 2 always (A/B, tests)
 };
 LaunchOverrides read_launch_overrides() {
     return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
-            env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0)};
+            env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
+            env_int("MMDX_SHARED_FUSED", 1)};
 }
 LaunchOverrides &launch_overrides() {
     static LaunchOverrides o = read_launch_overrides();
@@ -433,7 +436,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
                                           "(and only with them)");
     if (!a->palettes || !a->out_a || (layout != MMDX_OUT_VERTEX32 && !a->out_b))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "palettes / out_a / out_b is NULL");
-    if (p.ns && !a->morph_weights) return fail(MMDX_ERR_INVALID_ARGUMENT, "morph_weights is NULL");
+    if (p.ns && !a->morph_weights && !(a->flags & MMDX_MORPH_UNCHANGED))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "morph_weights is NULL");
     // host arguments: what kind of memory they are (device memory without its *_ON_DEVICE flag is a caller's
     // mistake that would otherwise end in a CPU memcpy from / to a device address)
     void *map_a = nullptr, *map_b = nullptr, *map_unused = nullptr;
@@ -506,13 +510,22 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     }
 
     // ---- morph mode + slot weights ----------------------------------------------------------------
+    // Morph mode.  Shared rates: a single frame and SMALL crowds with one facial state gather the morphs inside the deform
+    // kernel (every workgroup repeats its tile's walk; no separate launch: 8.8 vs 10.1 us for 2 instances of the 50k
+    // model, break-even at 8, tools/shared_ab.py); larger crowds run the morph pass once, in front (257 vs 269 us for
+    // 1024 instances) -- or not at all when the caller declares the rates unchanged since the last such call.
+    const bool unchanged = shared && ni > 1 && (a->flags & MMDX_MORPH_UNCHANGED);
+    if (unchanged && !m->morphed_valid)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "MMDX_MORPH_UNCHANGED without an earlier MMDX_WEIGHTS_SHARED crowd call on this model");
     int morph = kMorphNone;
-    if (p.ns) morph = shared ? (ni == 1 ? kMorphFused1 : kMorphShared) : kMorphFused4;
+    const int sf = launch_overrides().shared_fused;          // 0: never for crowds, 1: small crowds (default), 2: always
+    const bool gather_in_kernel = ni == 1 || (p.ns <= kMaxFusedSlots && !unchanged && (sf == 2 || (sf == 1 && ni <= 8)));
+    if (p.ns) morph = shared ? (gather_in_kernel ? kMorphFused1 : kMorphShared) : kMorphFused4;
     if (morph != kMorphNone) {
         const uint32_t niw = shared ? 1u : ni;
         const float *rates_dev;
-        if (a->flags & MMDX_WEIGHTS_ON_DEVICE) {
-            rates_dev = a->morph_weights;
+        if ((a->flags & MMDX_WEIGHTS_ON_DEVICE) || unchanged) {
+            rates_dev = a->morph_weights;                     // (unchanged: never read)
         } else {
             HIP_TRY(m->rates.ensure(size_t(niw) * p.nm * 4));
             HIP_TRY(copy_in(m, m->rates.ptr, a->morph_weights, kind_w, size_t(niw) * p.nm * 4, kBounceInBytes / 2, st));
@@ -531,10 +544,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (pev) HIP_TRY(hipEventRecord(pev[2], st));
         dp.wslot = f.out;
         dp.morphed = static_cast<float *>(m->morphed.ptr);
-        if (morph == kMorphShared && (a->flags & MMDX_MORPH_UNCHANGED)) {
-            if (!m->morphed_valid)
-                return fail(MMDX_ERR_INVALID_ARGUMENT, "MMDX_MORPH_UNCHANGED without an earlier MMDX_WEIGHTS_SHARED "
-                                                       "crowd call on this model");
+        if (morph == kMorphShared && unchanged) {
+            // nothing to launch: `morphed` holds the positions
         } else if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
             HIP_TRY(launch_morph_apply(p.f16, dp, &f, st));      // flatten fused in: one launch
         } else if (morph == kMorphFused1) {
@@ -546,7 +557,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
             if (morph == kMorphShared) HIP_TRY(launch_morph_apply(p.f16, dp, nullptr, st));
         }
         if (pev) HIP_TRY(hipEventRecord(pev[3], st));
-        if (morph == kMorphShared) m->morphed_valid = true;
+        if (morph == kMorphShared || (morph == kMorphFused1 && ni > 1)) m->morphed_valid = true;   // kept by either path
     }
 
     // ---- outputs ---------------------------------------------------------------------------------
@@ -602,7 +613,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // ---- group size (instances per workgroup) from the LDS budget ---------------------------------
     const uint32_t gmin = morph == kMorphFused4 ? (threads == 512 ? 8u : 4u) : 1u;
     uint32_t group = gmin;
-    if (morph != kMorphFused1) {
+    if (morph != kMorphFused1 || ni > 1) {
         const uint32_t target = uint32_t(ov.lds_target ? ov.lds_target : (morph == kMorphFused4 ? 64 : 42) * 1024);
         uint32_t so, wo;
         const size_t fixed = deform_lds_bytes(threads, layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);

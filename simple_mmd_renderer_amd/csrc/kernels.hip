@@ -202,11 +202,12 @@ struct RawEntry { using type = float4; };
 template <>
 struct RawEntry<true> { using type = uint2; };
 
-constexpr uint32_t kRowAhead = 4;   // entries in flight per lane; deeper (8) costs the fused kernels a wave per SIMD and loses: measured
+constexpr uint32_t kRowAhead = 4;   // entries in flight per lane in the deform kernels; deeper (8) costs the fused kernels a wave per
+                                    // SIMD and loses: measured.  The stand-alone morph pass has the registers for 16.
 
-template <bool F16>
-struct RowHead {                    // the first kRowAhead entries of a row, loaded ahead of their use
-    typename RawEntry<F16>::type e[kRowAhead];
+template <bool F16, uint32_t B = kRowAhead>
+struct RowHead {                    // the first B entries of a row, loaded ahead of their use
+    typename RawEntry<F16>::type e[B];
 };
 // Entry j of a row sits at byte (base + j*64) * sizeof(entry) of the table: a wave-uniform 64-bit base plus a 32-bit
 // per-lane offset (plan.cpp keeps the table under 4 GiB), so a lane carries one address register, not a pointer pair.
@@ -216,21 +217,21 @@ __device__ __forceinline__ typename RawEntry<F16>::type row_entry(const void *en
     const uint32_t off = (base + j * 64u) * uint32_t(sizeof(Raw));
     return *reinterpret_cast<const Raw *>(static_cast<const unsigned char *>(entries) + off);
 }
-template <bool F16>
-__device__ __forceinline__ void row_prefetch(const void *entries, uint32_t base, uint32_t len, RowHead<F16> &h) {
+template <bool F16, uint32_t B = kRowAhead>
+__device__ __forceinline__ void row_prefetch(const void *entries, uint32_t base, uint32_t len, RowHead<F16, B> &h) {
     using Raw = typename RawEntry<F16>::type;
     const uint32_t last = len ? len - 1 : 0u;
     // every element is (re)defined on every path, so that a head requested for the next pack is not kept alive
     // across the code in front of the request
 #pragma unroll
-    for (uint32_t i = 0; i < kRowAhead; ++i) {
+    for (uint32_t i = 0; i < B; ++i) {
         Raw v = Raw{};
         if (len) v = row_entry<F16>(entries, base, min(i, last));
         h.e[i] = v;
     }
 }
-template <bool F16, typename Body>
-__device__ __forceinline__ void row_consume(const void *entries, uint32_t base, uint32_t len, const RowHead<F16> &h,
+template <bool F16, uint32_t B = kRowAhead, typename Body>
+__device__ __forceinline__ void row_consume(const void *entries, uint32_t base, uint32_t len, const RowHead<F16, B> &h,
                                             Body body) {
     using Raw = typename RawEntry<F16>::type;
     auto apply = [&](const Raw r) {
@@ -242,7 +243,6 @@ __device__ __forceinline__ void row_consume(const void *entries, uint32_t base, 
     };
     // software-pipelined: the next B entries are in flight while the current B are consumed (the
     // gather is a chain of L2 round trips; with ~3 resident waves per SIMD nothing else hides them)
-    constexpr uint32_t B = kRowAhead;
     if (len == 0) return;
     const uint32_t last = len - 1;
     Raw cur[B], nxt[B];
@@ -262,11 +262,11 @@ __device__ __forceinline__ void row_consume(const void *entries, uint32_t base, 
         for (uint32_t i = 0; i < B; ++i) cur[i] = nxt[i];
     }
 }
-template <bool F16, typename Body>
+template <bool F16, uint32_t B = kRowAhead, typename Body>
 __device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint32_t len, Body body) {
-    RowHead<F16> h;
-    row_prefetch<F16>(entries, base, len, h);
-    row_consume<F16>(entries, base, len, h, body);
+    RowHead<F16, B> h;
+    row_prefetch<F16, B>(entries, base, len, h);
+    row_consume<F16, B>(entries, base, len, h, body);
 }
 
 // Group-morph recursion of one slot (UpdateMorphTransform, poser_impl.inl:328-339): rate[top] times the
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     // so that the workgroups running at the same time (neighbouring grp) write NEIGHBOURING instances:
     // chip-wide the stores then sweep a few contiguous megabytes of each output array, like a linear
     // fill, instead of 8+ streams 9.6 MB apart.
-    const bool ilv = (MORPH == kMorphNone || MORPH == kMorphShared) && p.interleave != 0;
+    const bool ilv = (MORPH == kMorphNone || MORPH == kMorphShared || MORPH == kMorphFused1) && p.interleave != 0;
     const uint32_t inst0 = ilv ? grp : grp * p.group;
     const uint32_t istep = ilv ? p.ngroups : 1u;
     const uint32_t gcount = ilv ? (p.ni > grp ? min(p.group, (p.ni - grp + p.ngroups - 1) / p.ngroups) : 0u)
@@ -519,14 +519,28 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     // 2. morph slot weights of the group -> LDS
     if constexpr (MORPH == kMorphFused1) {
         float *wl = reinterpret_cast<float *>(smem + p.w_off);
-        if (p.fused_rates) {   // single-instance call: flatten in here, no separate launch
-            const float *rates = p.fused_rates + size_t(inst0) * p.nm;
+        // ONE set of morph rates for the whole launch (a single-model frame, or a crowd that shares its facial state)
+        if (p.fused_rates) {   // flatten the group morphs in here, no separate launch
             for (uint32_t s = tid; s <= p.ns; s += THREADS)
-                wl[s] = s < p.ns ? slot_weight(rates, p.slot_top, p.chain_off, p.chain_rate, s) : 0.f;
+                wl[s] = s < p.ns ? slot_weight(p.fused_rates, p.slot_top, p.chain_off, p.chain_rate, s) : 0.f;
         } else {
-            for (uint32_t s = tid; s <= p.ns; s += THREADS) wl[s] = p.wslot[size_t(inst0) * (p.ns + 1) + s];
+            for (uint32_t s = tid; s <= p.ns; s += THREADS) wl[s] = p.wslot[s];
         }
-    }   // kMorphFused4 stages the weights of one instance quad at a time, inside the quad loop
+    }
+    // kMorphFused4: slot weights of one PACK of instances (kQuads quads of four) at a time; the first pack's are
+    // requested here, under the set-up's other loads
+    constexpr int kQuads = VPT == 1 ? 2 : 1, kPack = 4 * kQuads;
+    const uint32_t wstride = p.ns + 1, wcount = uint32_t(kQuads) * wstride;
+    // float4 i of the weights of the pack that starts at group instance g0 (a missing second quad reads as zeros:
+    // weight +0 adds nothing, bit for bit; its instances are never written out)
+    auto pack_weight = [&](uint32_t g0, uint32_t i) {
+        const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t((inst0 + g0) / 4) * wstride;
+        return (i < wstride || g0 + 4 < gcount) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if constexpr (MORPH == kMorphFused4) {
+        float4 *wq0 = reinterpret_cast<float4 *>(smem + p.w_off);
+        for (uint32_t i = tid; i < wcount && gcount; i += THREADS) wq0[i] = pack_weight(0, i);
+    }
 
     // 3. static per-vertex data -> registers (sorted slot s = tid + k*THREADS)
     Slot sl[VPT];
@@ -564,33 +578,32 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                 if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
             });
             cxy[k] = sl[k].pxy + dxy; cz[k] = sl[k].pz + dz;
+            // the morphed positions are kept (sorted order) for later calls that declare the rates unchanged
+            if (grp == 0 && p.morphed && sl[k].act) {
+                float *mo = p.morphed + (size_t(v0) + uint32_t(tid) + uint32_t(k) * THREADS) * 3;
+                mo[0] = cxy[k].x; mo[1] = cxy[k].y; mo[2] = cz[k];
+            }
         }
-        run_instance(0, cxy, cz);
+        // the group's instances: one for a single-model frame; for a crowd with a shared facial state every workgroup
+        // repeats its tile's short walk (the table stays in its XCD's L2) instead of waiting for a separate morph pass
+        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cxy, cz);
     } else {
         // Slot weights of kQuads instance quads live in LDS at a time (kQuads x (NS+1) x float4): one pass over
         // a vertex's morph row then serves 4*kQuads instances, so the table is walked (and its L2 latency paid)
         // that much less often.  One slot per lane (512 threads) has the registers for two quads; two slots per
-        // lane do not (a third wave per SIMD is worth more there: measured).  A missing second quad is staged as
-        // zeros: weight +0 adds nothing, bit for bit.  The accumulators pair x with y of ONE instance; pairing two
+        // lane do not (a third wave per SIMD is worth more there: measured).  The accumulators pair x with y of ONE instance; pairing two
         // instances per component instead (three packed multiply-adds per entry and instance pair, a quarter fewer
         // instructions) measured 10 % slower: v_pk_mul_f32 / v_pk_add_f32 occupy the SIMD for two passes, so the
         // arithmetic time is the same and the position fix-up comes on top.
-        constexpr int kQuads = VPT == 1 ? 2 : 1, kPack = 4 * kQuads;
         float4 *wq = reinterpret_cast<float4 *>(smem + p.w_off);
-        const uint32_t wstride = p.ns + 1;
+        // The first pack's weights were staged during the set-up.  When one float4 per thread covers a pack's weights,
+        // the NEXT pack's are fetched into a register before this pack's instances are skinned and reach LDS after
+        // them: their load round trip is hidden and one barrier separates the packs.  (Otherwise: staged between the
+        // packs.)
+        const bool wreg = wcount <= uint32_t(THREADS);
         for (uint32_t g0 = 0; g0 < gcount; g0 += kPack) {
             v2f dxy[VPT][kPack];
             float dz[VPT][kPack];
-            if (g0) __syncthreads();                       // everyone is done with the previous weights
-            {
-                const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t((inst0 + g0) / 4) * wstride;
-                for (uint32_t i = tid; i < wstride; i += THREADS) {
-                    wq[i] = src[i];
-                    if constexpr (kQuads == 2)
-                        wq[wstride + i] = g0 + 4 < gcount ? src[wstride + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            __syncthreads();
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
 #pragma unroll
@@ -625,6 +638,9 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     });
                 }
             }
+            const bool more = g0 + kPack < gcount;
+            float4 wnext = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (more && wreg && uint32_t(tid) < wcount) wnext = pack_weight(g0 + kPack, uint32_t(tid));
 #pragma unroll
             for (int j = 0; j < kPack; ++j) {
                 if (g0 + j < gcount) {
@@ -636,6 +652,16 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     }
                     run_instance(g0 + j, cxy, cz);
                 }
+            }
+            if (more) {
+                // every wave has left this pack's walk (it passed the barriers of the pack's instances): the weights can
+                // be replaced; one barrier before the next walk reads them
+                if (wreg) {
+                    if (uint32_t(tid) < wcount) wq[tid] = wnext;
+                } else {
+                    for (uint32_t i = tid; i < wcount; i += THREADS) wq[i] = pack_weight(g0 + kPack, i);
+                }
+                __syncthreads();
             }
         }
     }
@@ -669,7 +695,8 @@ __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParam
     v2f dxy = v2f{0.f, 0.f};
     float dz = 0.f;
     const uint2 sl2 = p.ell[gs >> 6];
-    for_row<F16>(p.entries, sl2.x + uint32_t(gs & 63), sl2.y, [&](float ox, float oy, float oz, uint32_t slot) {
+    // a thread of this pass has nothing else in its registers: 16 entries in flight cover most rows in one round trip
+    for_row<F16, 16>(p.entries, sl2.x + uint32_t(gs & 63), sl2.y, [&](float ox, float oy, float oz, uint32_t slot) {
         const float w = wsl[slot];
         if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
     });

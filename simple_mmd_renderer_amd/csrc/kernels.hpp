@@ -15,7 +15,8 @@ enum : int {
     kMorphNone = 0,     // model has no vertex-morph slot
     kMorphShared = 1,   // positions come from the `morphed` buffer written by morph_apply (crowd
                         // with one shared facial state: the morph pass runs once per call)
-    kMorphFused1 = 2,   // per-instance weights, one instance at a time (single deform)
+    kMorphFused1 = 2,   // ONE set of morph rates for the launch, gathered inside the deform kernel: a single-model frame,
+                        // or a crowd with a shared facial state (every workgroup repeats its tile's walk)
     kMorphFused4 = 3    // per-instance weights, 4 instances share one pass over a CSR row
 };
 

@@ -763,3 +763,48 @@ def test_vmd_to_crowd_end_to_end(oracle):
             b.free()
     mm.close()
 
+
+
+@pytest.mark.parametrize("ni,fused", [(21, "1"), (21, "2"), (5, "1"), (5, "0")])
+def test_shared_crowd_paths_agree_and_unchanged_flag(oracle, monkeypatch, ni, fused):
+    """A crowd with a shared facial state has three routes -- the morph gather inside the deform kernel (small crowds;
+    MMDX_SHARED_FUSED=2 forces it), the separate morph pass, and the kept morphed positions with MMDX_MORPH_UNCHANGED --
+    all bit-identical to the oracle; UNCHANGED before any shared call is an error; after new weights the kept
+    positions are the new ones."""
+    monkeypatch.setenv("MMDX_SHARED_FUSED", fused)
+    api.lib().mmdx_debug_reload_env()
+    m = synth.make_model(3000, 50, 7, 250, seed=555)
+    pals = synth.make_palettes(m, np.arange(ni) * 3)
+    r1, r2 = synth.morph_weights(m.nm, 5)[0], synth.morph_weights(m.nm, 40)[0]
+    skin = oracle.normalize(m)
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    with DeformModel(m) as dm:
+        d_pal = DeviceBuffer.from_numpy(pals)
+        d_w1, d_w2 = DeviceBuffer.from_numpy(r1), DeviceBuffer.from_numpy(r2)
+        sa, sb = dm.out_sizes(api.OUT_SOA, ni)
+        d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+
+        def check(rates, what):
+            dm.sync()
+            pos, nrm = d_a.download((ni, m.nv, 3), np.float32), d_b.download((ni, m.nv, 3), np.float32)
+            vimg = oracle.morph(m, rates)
+            for i in range(ni):
+                ep, en = oracle.skin(m, pals[i], vimg, skin)
+                gu.assert_bits_equal(pos[i], ep, f"{what} inst {i} pos")
+                gu.assert_bits_equal(nrm[i], en, f"{what} inst {i} nrm")
+            d_a.memset(0); d_b.memset(0)
+
+        with pytest.raises(api.MmdxError, match="UNCHANGED"):
+            dm.deform_batched_raw(ni, None, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags | api.MORPH_UNCHANGED)
+        dm.deform_batched_raw(ni, d_w1.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+        check(r1, "gather in the kernel")
+        dm.deform_batched_raw(ni, None, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags | api.MORPH_UNCHANGED)
+        check(r1, "unchanged (weights pointer NULL)")
+        dm.deform_batched_raw(ni, d_w2.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+        check(r2, "new weights")
+        dm.deform_batched_raw(ni, d_w1.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags | api.MORPH_UNCHANGED)
+        check(r2, "unchanged after new weights (the pointer passed is ignored)")
+        for b in (d_pal, d_w1, d_w2, d_a, d_b):
+            b.free()
+    monkeypatch.delenv("MMDX_SHARED_FUSED")
+    api.lib().mmdx_debug_reload_env()
