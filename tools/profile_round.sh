@@ -8,10 +8,13 @@
 # rocprofv3 is always given the program itself after "--" (python3 ...), never a wrapper.
 set -e -o pipefail
 tag=${1:-r02}
+from=${2:-1}            # 1: everything; 6: from the all-workloads trace on (stages 1-5 already collected)
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py --steps 50 --warmup 5 > $out/bench.json
+export MMDX_BENCH_NO_GRAPH=1     # rocprofv3's tracer segfaults on hipStreamBeginCapture (ROCm 7.2): the graph leg of the extras is left out
+if [ "$from" -le 1 ]; then
+env -u MMDX_BENCH_NO_GRAPH python3 bench.py --steps 50 --warmup 5 > $out/bench.json
 B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B > $out/bench_under_rocprof.json 2> $out/rocprof.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o fetch -- $B > /dev/null 2>&1
@@ -19,6 +22,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_sq1 -o sq1 -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $out/pmc_sq2 -o sq2 -- $B > /dev/null 2>&1
 echo "crowd passes done" >&2
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_all -o all -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $out/rocprof_all.log
 echo "all-workloads trace done" >&2
 F="python3 tools/fused_bench.py c2 c5 c3p --iters 10"
