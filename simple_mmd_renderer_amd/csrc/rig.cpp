@@ -388,17 +388,21 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
     {
         std::vector<uint32_t> depth(nb, 0);                 // 0 = not computed
         std::vector<uint8_t> on_path(nb, 0);
-        std::function<int64_t(uint32_t)> nest = [&](uint32_t x) -> int64_t {
+        // returns the nesting depth of x's solve (0: not an IK bone), -1 for a cycle, -2 for a nest deeper than the device
+        // code unrolls; `level` = solves already on the stack, so the recursion itself never goes deeper than that limit
+        // (a file may chain a million IK bones)
+        std::function<int64_t(uint32_t, uint32_t)> nest = [&](uint32_t x, uint32_t level) -> int64_t {
             if (!(out.bones[x].bits & kBoneHasIk)) return 0;
             if (on_path[x]) return -1;
+            if (level >= kMaxIkDepth) return -2;
             if (depth[x]) return depth[x];
             on_path[x] = 1;
             IkRec &ik = out.iks[out.bones[x].ik];
             int64_t deepest = 0;
             for (uint32_t j = 0; j <= ik.nlinks; ++j) {
                 const uint32_t y = j < ik.nlinks ? out.links[ik.link0 + j].bone : ik.target;
-                const int64_t dd = nest(y);
-                if (dd < 0) return -1;
+                const int64_t dd = nest(y, level + 1);
+                if (dd < 0) { on_path[x] = 0; return dd; }
                 if (dd > 0) { ik.nested = 1; out.nested_ik = true; }
                 deepest = std::max(deepest, dd);
             }
@@ -407,10 +411,10 @@ mmdx_status build_skeleton(const mmdx_skeleton_desc &d, SkeletonPlan &out, std::
             return depth[x];
         };
         for (uint32_t b = 0; b < nb; ++b) {
-            const int64_t dd = nest(b);
-            if (dd < 0) return bad(MMDX_ERR_UNSUPPORTED, "IK bone " + std::to_string(b) + " is (indirectly) a link or target of its own "
-                                                         "solve: the reference recurses without end");
-            if (dd > int64_t(kMaxIkDepth))
+            const int64_t dd = nest(b, 0);
+            if (dd == -1) return bad(MMDX_ERR_UNSUPPORTED, "IK bone " + std::to_string(b) + " is (indirectly) a link or target of its own "
+                                                           "solve: the reference recurses without end");
+            if (dd == -2 || dd > int64_t(kMaxIkDepth))
                 return bad(MMDX_ERR_UNSUPPORTED, "IK solves nested more than " + std::to_string(kMaxIkDepth) + " deep at bone " + std::to_string(b));
         }
     }

@@ -273,9 +273,11 @@ int main() {
         d.struct_size = sizeof(d); d.n_bones = nb;
         d.rest_position = rest.data(); d.parent = par.data();
         d.transform_level = it % 3 ? lvl.data() : nullptr; d.flags = it % 2 ? fl.data() : nullptr;
+        d.create_flags = it % 5 == 0 ? MMDX_SKELETON_PHYSICS_SEAM : 0;   // forces the ordered solver's tables for any rig
         mmdx::SkeletonPlan sp;
         std::string err;
-        // IK / append tables, with some indices out of range on purpose
+        // IK / append tables, with some indices out of range on purpose (targets / links may be IK bones themselves:
+        // nested solves up to 3 deep are scheduled, cycles and deeper nests rejected)
         std::vector<int32_t> app(nb + 1), tgt(nb + 1), loop(nb + 1), lbone;
         std::vector<float> ratio(nb + 1, 0.5f), ang(nb + 1, 1.0f), lim;
         std::vector<uint32_t> loff(nb + 2, 0);
@@ -319,6 +321,28 @@ int main() {
         } else ++sk_bad;
     }
     std::printf("skeleton: compiled=%d rejected=%d; ordered solver: %d events in %d rounds\n", sk_ok, sk_bad, sk_events, sk_rounds);
+    {   // 200 000 IK bones, each the target of the previous one: the nesting check must reject it without recursing
+        // 200 000 frames deep; the same chain closed into a ring is a cycle
+        const uint32_t nb = 200000;
+        std::vector<float> rest(size_t(nb) * 3, 0.5f), ang(nb, 1.0f);
+        std::vector<int32_t> par(nb, -1), tgt(nb), loop(nb, 1), lbone;
+        std::vector<uint16_t> fl(nb, 0x0020);
+        std::vector<uint32_t> loff(nb + 1, 0);
+        std::vector<uint8_t> limited(1, 0);
+        lbone.push_back(0);
+        for (uint32_t b = 0; b < nb; ++b) tgt[b] = int32_t(b + 1 < nb ? b + 1 : b);
+        fl[nb - 1] = 0;                                         // the last one is a plain bone
+        mmdx_skeleton_desc d{};
+        d.struct_size = sizeof(d); d.n_bones = nb; d.rest_position = rest.data(); d.parent = par.data(); d.flags = fl.data();
+        d.ik_target = tgt.data(); d.ik_loop_count = loop.data(); d.ik_angle_limit = ang.data();
+        d.ik_link_offset = loff.data(); d.ik_link_bone = lbone.data(); d.ik_link_limited = limited.data();
+        mmdx::SkeletonPlan sp;
+        std::string err;
+        if (mmdx::build_skeleton(d, sp, err) != MMDX_ERR_UNSUPPORTED) return 14;
+        fl[nb - 1] = 0x0020; tgt[nb - 1] = 0;                   // a ring
+        if (mmdx::build_skeleton(d, sp, err) != MMDX_ERR_UNSUPPORTED) return 15;
+        std::printf("deep / cyclic IK nests rejected: %s\n", err.c_str());
+    }
     return 0;
 }
 
