@@ -140,15 +140,33 @@ public:
         if (index * 8 + 8 > bone_poses_.size()) throw Error(MMDX_ERR_BAD_INDEX, "SetBonePose: bone index out of range");
         std::memcpy(q, translation, 12); q[3] = 0.0f; std::memcpy(q + 4, rotation, 16);
     }
-    // Bone solve on the device (bone morphs, append bones, IK included): local poses -> skinning matrices.
-    // Only for posers that own a rig (FromFile); physics, if any, stays with the host, which overwrites
-    // its bones' rows through SkinningMatrix() between the two calls exactly as mmd-bullet does today.
+    // Bone solve on the device (bone morphs, append bones, IK incl. nested IK): local poses -> skinning matrices, in the
+    // reference's two steps (main.cpp:1801-1810).  Only for posers that own a rig (FromFile).  PrePhysicsPosing() runs
+    // the pre-physics bone list; SkinningMatrix(b) of those bones is then what a reactor's kinematic bodies read
+    // (PoserMotionState::Reset).  A reactor hands the transforms of the bodies it moved to SetPhysicsTransforms() --
+    // what PoserMotionState::Synchronize() writes, with `strict` marking the bodies Fix() applies to
+    // (mmd-bullet_impl.inl:34-56) -- and PostPhysicsPosing() applies them and runs the post-physics list.
     void PrePhysicsPosing() {
         if (!skeleton_) throw Error(MMDX_ERR_UNSUPPORTED, "this Poser has no rig: fill SkinningMatrix() yourself");
-        check(mmdx_skeleton_solve_morphed(skeleton_, model_, 1, bone_poses_.data(), nm_ ? morph_rates_.data() : nullptr,
-                                          MMDX_WEIGHTS_SHARED, palette_.data()));
+        check(mmdx_skeleton_solve_pre(skeleton_, model_, 1, bone_poses_.data(), nm_ ? morph_rates_.data() : nullptr,
+                                      MMDX_WEIGHTS_SHARED, palette_.data()));
+        physics_bones_.clear(); physics_strict_.clear(); physics_skinning_.clear();
     }
-    void PostPhysicsPosing() {}   // the device solve covers both of the reference's bone lists in order
+    void SetPhysicsTransforms(const std::vector<int32_t> &bones, const std::vector<uint8_t> &strict,
+                              const float *skinning /*[bones.size()][16]*/) {
+        physics_bones_ = bones;
+        physics_strict_ = strict;
+        physics_strict_.resize(bones.size(), 0);
+        physics_skinning_.assign(skinning, skinning + bones.size() * 16);
+    }
+    void PostPhysicsPosing() {
+        if (!skeleton_) throw Error(MMDX_ERR_UNSUPPORTED, "this Poser has no rig: fill SkinningMatrix() yourself");
+        mmdx_physics_overrides ov;
+        ov.struct_size = sizeof(ov);
+        ov.n_bones = uint32_t(physics_bones_.size());
+        ov.bone = physics_bones_.data(); ov.strict = physics_strict_.data(); ov.skinning = physics_skinning_.data();
+        check(mmdx_skeleton_solve_post(skeleton_, model_, 1, ov.n_bones ? &ov : nullptr, 0, palette_.data()));
+    }
 
     const std::vector<std::string> &bone_names() const { return bone_names_; }
     const std::vector<std::string> &morph_names() const { return morph_names_; }
@@ -191,6 +209,7 @@ private:
         check(mmdx_model_create(&d, &model_));
         mmdx_skeleton_desc sd;
         check(mmdx_pmx_get_skeleton_desc(pmx, &sd));
+        sd.create_flags |= MMDX_SKELETON_PHYSICS_SEAM;      // PrePhysicsPosing | a reactor's writes | PostPhysicsPosing
         const mmdx_status st = mmdx_skeleton_create(&sd, &skeleton_);
         if (st != MMDX_OK) { mmdx_model_destroy(model_); throw Error(st, mmdx_last_error_string()); }
         char buf[1024];
@@ -209,6 +228,9 @@ private:
     mmdx_model_t model_ = nullptr;
     mmdx_skeleton_t skeleton_ = nullptr;
     std::vector<float> morph_rates_, palette_, bone_poses_;
+    std::vector<int32_t> physics_bones_;                  // what a reactor moved this frame (SetPhysicsTransforms)
+    std::vector<uint8_t> physics_strict_;
+    std::vector<float> physics_skinning_;
     std::vector<std::string> bone_names_, morph_names_;
 };
 
