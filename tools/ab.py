@@ -35,7 +35,7 @@ def main():
     rates = synth.morph_weights(model.nm, 30)[0]
     dm = DeformModel(model)
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
-    d_a, d_b, placement = dm.alloc_outputs(layout, ni, 24)     # fast placement mode
+    d_a, d_b, placement = dm.alloc_outputs(layout, ni, int(os.environ.get("AB_TRIES", "24")))   # AB_TRIES=1: whatever hipMalloc hands out first
     print("output placement:", placement, flush=True)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
     dense = os.environ.get("AB_DENSE") == "1"
