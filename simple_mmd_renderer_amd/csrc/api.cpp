@@ -182,13 +182,16 @@ int env_int(const char *name, int dflt) {
 // per-frame call has a budget of a few microseconds and getenv walks the whole environment.
 struct LaunchOverrides {
     int interleave, threads, lds_target, group, placement_log, placement_park;
+    int frame_kernel;   // MMDX_FRAME_KERNEL: 0 = a single frame always runs the tile kernel, 1 = models of fewer than 256 tiles run the
+                        // frame kernel (default), 2 = always (A/B); MMDX_FRAME_THREADS: 128 / 256 lanes per workgroup
+    int frame_threads;
     int shared_fused;   // MMDX_SHARED_FUSED: crowds with a shared facial state gather the morphs inside the deform kernel: 0 never,
                         // 1 up to 8 instances (default), 2 always (A/B, tests)
 };
 LaunchOverrides read_launch_overrides() {
     return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
             env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
-            env_int("MMDX_SHARED_FUSED", 1)};
+            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1)};
 }
 LaunchOverrides &launch_overrides() {
     static LaunchOverrides o = read_launch_overrides();
@@ -605,7 +608,10 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // ---- workgroup shape ------------------------------------------------------------------------------
     // 256 threads / two vertex slots per lane everywhere except the per-instance-morph path: there one slot
     // per lane (512 threads) leaves the registers to serve 8 instances per walk over a morph row.
-    int threads = (ov.threads ? ov.threads : (morph == kMorphFused4 ? 512 : 256)) == 512 ? 512 : 256;
+    // A single frame (one instance) is latency-bound: one slot per lane and twice the waves per tile finish sooner
+    // (config 2: 8.4 -> 6.9 us, config 5: 16.9 -> 14.9 us).
+    const bool one_frame = ni == 1 && (morph == kMorphNone || morph == kMorphFused1);
+    int threads = (ov.threads ? ov.threads : (morph == kMorphFused4 || one_frame ? 512 : 256)) == 512 ? 512 : 256;
     if (morph == kMorphFused4 && threads == 512) {   // tiles with hundreds of bones: 8 palettes do not fit, 4 may
         uint32_t so, wo;
         if (deform_lds_bytes(512, layout, morph, 8, p.max_tile_bones, p.ns, &so, &wo) > 160 * 1024) threads = 256;
@@ -641,7 +647,21 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
                                           "too many distinct bones in one vertex tile / too many morph slots");
 
     if (pev) HIP_TRY(hipEventRecord(pev[0], st));
-    HIP_TRY(launch_deform(threads, int(layout), morph, p.f16, dp, p.ntiles, lds, st));
+    // One frame of one model into device memory: the latency-ordered kernel (parts of tiles on every CU, direct stores).
+    // Outputs in mapped host memory keep the tile kernel: its 16-byte coalesced stores are what crosses PCIe well.
+    // Models with fewer tiles than the chip has CUs only (config 2: 6.3 us against the tile kernel's 6.9); a large model fills the
+    // chip with whole tiles and is better off with their coalesced stores (config 5: 14.9 us against 15.2).
+    const bool frame = one_frame && !out_direct && !out_bounce && (ov.frame_kernel == 2 || (ov.frame_kernel == 1 && p.ntiles < 256));
+    if (frame) {
+        DeformParams fp = dp;
+        fp.morphed = nullptr;                                  // nothing reads a single frame's morphed positions later
+        const size_t flds = frame_lds_bytes(morph, p.max_tile_bones, p.ns, &fp.w_off);
+        if (flds > 160 * 1024)
+            return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(flds) + " bytes of LDS (> 160 KiB)");
+        HIP_TRY(launch_frame(ov.frame_threads, int(layout), morph, p.f16, fp, p.ntiles, flds, st));
+    } else {
+        HIP_TRY(launch_deform(threads, int(layout), morph, p.f16, dp, p.ntiles, lds, st));
+    }
     if (pev) {
         HIP_TRY(hipEventRecord(pev[1], st));
         if (m->prof_has_morph.size() <= m->prof_calls) m->prof_has_morph.resize(m->prof_calls + 1);

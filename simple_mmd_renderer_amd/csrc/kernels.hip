@@ -386,6 +386,142 @@ __device__ __forceinline__ void stage_palettes(const DeformParams &p, const Tile
     }
 }
 
+// Set-up of the one-set-of-rates kernel (kMorphFused1: a single-model frame, small crowds with a shared facial state), ordered
+// for LATENCY: such a launch is a handful of workgroups whose run time is the length of their chain of dependent memory round
+// trips (config 2, one frame: 9.6 MB in ~8 us).  Everything that depends on the tile header only is requested first (static
+// vertex data, bone ids of the palette rows, slot tables), then everything that depends on those (the first BH entries of the
+// threads' morph rows, the palette rows, the morph rates), and only then does anything wait: two round trips instead of the six
+// or seven of "palettes, then weights, then vertices, then rows".  One batch of kPalBatch palette rows / kWgtBatch slots per
+// thread is handled this way; what does not fit (large groups, thousands of slots) follows in plain loops.
+constexpr int kPalBatch = 4, kWgtBatch = 4;
+
+template <int THREADS, int LAYOUT, int MORPH, bool F16, int VPT, uint32_t BH>
+__device__ __forceinline__ void setup_fused1(const DeformParams &p, const TileHdr &th, float4 *pal, float *wl, uint32_t inst0,
+                                             uint32_t istep, uint32_t gcount, int tid, uint32_t slot_base, Slot (&sl)[VPT],
+                                             RowHead<F16, BH> (&hd)[VPT]) {
+    constexpr bool kWalk = MORPH == kMorphFused1;         // kMorphNone: palettes and static data only
+    const uint32_t nb4 = th.nbt * 4u, rows = gcount * nb4, ns = p.ns;
+    const uint32_t *bones = p.bone_list + th.bone_off;
+    const bool flat = p.fused_rates == nullptr;          // slot weights already evaluated (p.wslot)
+    // palette row e = (instance g of the group, tile bone lb, matrix row r): e = (g * nbt + lb) * 4 + r
+    auto row_src = [&](uint32_t e, uint32_t bone) {
+        const uint32_t g = gcount == 1 ? 0u : e / nb4;
+        return reinterpret_cast<const float4 *>(p.palettes + size_t(inst0 + g * istep) * p.nb * 16 + size_t(bone) * 16 + (e & 3u) * 4);
+    };
+    auto row_put = [&](uint32_t e, const float4 row) {
+        const uint32_t g = gcount == 1 ? 0u : e / nb4, rem = e - g * nb4, lb = rem >> 2, r = rem & 3u;
+        // entry = {m00 m01 | m10 m11} {m20 m21 | m30 m31} {m02 m12 | m22 m32}; this element is row r
+        float *en = reinterpret_cast<float *>(pal + size_t(g) * p.pal_stride) + lb * 12;
+        *reinterpret_cast<float2 *>(en + (r >> 1) * 4 + (r & 1u) * 2) = make_float2(row.x, row.y);
+        en[8 + r] = row.z;
+    };
+    auto chain = [&](float r, uint32_t c0, uint32_t c1) {     // slot_weight() from the rate of the slot's top-level morph on
+        bool skip = r < kMorphEps;
+        for (uint32_t c = c0; !skip && c < c1; ++c) {
+            r = p.chain_rate[c] * r;
+            skip = r < kMorphEps;
+        }
+        return skip ? 0.f : r;
+    };
+
+    // ---- round trip 1: static vertex data, bone ids, slot tables ---------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) load_slot<LAYOUT, MORPH, F16>(p, th, slot_base + uint32_t(tid) + uint32_t(k) * THREADS, sl[k]);
+    uint32_t bone[kPalBatch];
+#pragma unroll
+    for (int i = 0; i < kPalBatch; ++i) {
+        const uint32_t e = uint32_t(tid) + uint32_t(i) * THREADS;
+        bone[i] = e < rows ? bones[((gcount == 1 ? e : e % nb4)) >> 2] : 0u;
+    }
+    uint32_t top[kWgtBatch], c0[kWgtBatch], c1[kWgtBatch];
+    float wv[kWgtBatch];
+#pragma unroll
+    for (int i = 0; i < kWgtBatch; ++i) {
+        const uint32_t sidx = uint32_t(tid) + uint32_t(i) * THREADS;
+        top[i] = c0[i] = c1[i] = 0u;
+        wv[i] = 0.f;
+        if (kWalk && sidx < ns) {
+            if (flat) wv[i] = p.wslot[sidx];
+            else { top[i] = p.slot_top[sidx]; c0[i] = p.chain_off[sidx]; c1[i] = p.chain_off[sidx + 1]; }
+        }
+    }
+    // ---- round trip 2: the heads of the morph rows, the palette rows, the rates ---------------------------------------------
+    if constexpr (kWalk) {
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) row_prefetch<F16, BH>(p.entries, sl[k].rb, sl[k].rlen, hd[k]);
+    }
+    float4 row[kPalBatch];
+#pragma unroll
+    for (int i = 0; i < kPalBatch; ++i) {
+        const uint32_t e = uint32_t(tid) + uint32_t(i) * THREADS;
+        row[i] = e < rows ? *row_src(e, bone[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (kWalk && !flat) {
+#pragma unroll
+        for (int i = 0; i < kWgtBatch; ++i)
+            if (uint32_t(tid) + uint32_t(i) * THREADS < ns) wv[i] = p.fused_rates[top[i]];
+    }
+    // ---- into LDS -----------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < kPalBatch; ++i) {
+        const uint32_t e = uint32_t(tid) + uint32_t(i) * THREADS;
+        if (e < rows) row_put(e, row[i]);
+    }
+    if constexpr (kWalk) {
+#pragma unroll
+        for (int i = 0; i < kWgtBatch; ++i) {
+            const uint32_t sidx = uint32_t(tid) + uint32_t(i) * THREADS;
+            if (sidx <= ns) wl[sidx] = sidx < ns ? (flat ? wv[i] : chain(wv[i], c0[i], c1[i])) : 0.f;   // slot ns = table padding, weight 0
+        }
+    }
+    // ---- what did not fit the first batch -------------------------------------------------------------------------------------
+    for (uint32_t e = uint32_t(kPalBatch) * THREADS + uint32_t(tid); e < rows; e += THREADS)
+        row_put(e, *row_src(e, bones[(e % nb4) >> 2]));
+    if constexpr (kWalk) {
+        for (uint32_t sidx = uint32_t(kWgtBatch) * THREADS + uint32_t(tid); sidx <= ns; sidx += THREADS)
+            wl[sidx] = sidx < ns ? (flat ? p.wslot[sidx] : slot_weight(p.fused_rates, p.slot_top, p.chain_off, p.chain_rate, sidx)) : 0.f;
+    }
+}
+
+// The vertex's blended palette matrix: BDEF1 the bone's, BDEF2-like Lerp(S[b1], S[b0])[w] with the epsilon short circuits,
+// BDEF4 ((S0*w0 + S1*w1) + S2*w2) + S3*w3 (poser_impl.inl:412-434).  P = the instance's palette in LDS.
+__device__ __forceinline__ M12 skin_matrix(const Slot &q, const float4 *P) {
+    M12 m;
+    if (q.cls == 0) {
+        m = load_m12(P, q.b0);
+    } else if (q.cls == 1) {
+        // Lerp(S[b1], S[b0])[w]  (poser_impl.inl:420-422, math_impl.inl:1246-1254)
+        const M12 a = load_m12(P, q.b1), e = load_m12(P, q.b0);
+        const float l = q.w0;
+        m = blend2(a, e, 1.0f - l, l);
+        // epsilon short-circuits: rare, so only waves that hold such a weight pay for them
+        const bool lo = l < kLerpLo, hi = l > kLerpHi;
+        if (__builtin_amdgcn_ballot_w64(lo || hi) != 0) {
+            if (lo) m = a;
+            else if (hi) m = e;
+        }
+    } else {
+        // ((S0*w0 + S1*w1) + S2*w2) + S3*w3, two palette entries in registers at a time: the scheduler would
+        // otherwise issue all twelve LDS reads first and hold four matrices (48 VGPRs) at once -- the peak
+        // of the kernel's register pressure
+        {
+            const M12 a = load_m12(P, q.b0), b = load_m12(P, q.b1);
+            m = mul_add(a, q.w0, b, q.w1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const M12 c = load_m12(P, q.b2);
+            m = add_mul(m, c, q.w2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const M12 d = load_m12(P, q.b3);
+            m = add_mul(m, d, q.w3);
+        }
+    }
+    return m;
+}
+
 // One instance: skin the thread's slots with the palette at P (LDS), scatter the results to the LDS image `img`
 // (undoing the class sort), ONE workgroup barrier, then write the image out with coalesced 16-byte stores.
 // `inst` = the instance's index in the output arrays, cxy / cz = the (morphed) positions of the thread's slots.
@@ -401,39 +537,7 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
     for (int k = 0; k < VPT; ++k) {
         const Slot &q = sl[k];
         if (!q.act) continue;
-        M12 m;
-        if (q.cls == 0) {
-            m = load_m12(P, q.b0);
-        } else if (q.cls == 1) {
-            // Lerp(S[b1], S[b0])[w]  (poser_impl.inl:420-422, math_impl.inl:1246-1254)
-            const M12 a = load_m12(P, q.b1), e = load_m12(P, q.b0);
-            const float l = q.w0;
-            m = blend2(a, e, 1.0f - l, l);
-            // epsilon short-circuits: rare, so only waves that hold such a weight pay for them
-            const bool lo = l < kLerpLo, hi = l > kLerpHi;
-            if (__builtin_amdgcn_ballot_w64(lo || hi) != 0) {
-                if (lo) m = a;
-                else if (hi) m = e;
-            }
-        } else {
-            // ((S0*w0 + S1*w1) + S2*w2) + S3*w3, two palette entries in registers at a time: the scheduler would
-            // otherwise issue all twelve LDS reads first and hold four matrices (48 VGPRs) at once -- the peak
-            // of the kernel's register pressure
-            {
-                const M12 a = load_m12(P, q.b0), b = load_m12(P, q.b1);
-                m = mul_add(a, q.w0, b, q.w1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const M12 c = load_m12(P, q.b2);
-                m = add_mul(m, c, q.w2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const M12 d = load_m12(P, q.b3);
-                m = add_mul(m, d, q.w3);
-            }
-        }
+        const M12 m = skin_matrix(q, P);
         v2f oxy, rxy;
         float oz, rz;
         xform_pos(m, cxy[k], cz[k], oxy, oz);
@@ -514,19 +618,10 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     unsigned char *stage = smem + p.stage_off;
     constexpr uint32_t kStage = stage_bytes(LAYOUT);
 
-    // 1. bone palettes of the group's instances -> LDS: only the tile's bones, in the pair layout
-    stage_palettes<THREADS>(p, th, pal, inst0, istep, gcount, tid);
-    // 2. morph slot weights of the group -> LDS
-    if constexpr (MORPH == kMorphFused1) {
-        float *wl = reinterpret_cast<float *>(smem + p.w_off);
-        // ONE set of morph rates for the whole launch (a single-model frame, or a crowd that shares its facial state)
-        if (p.fused_rates) {   // flatten the group morphs in here, no separate launch
-            for (uint32_t s = tid; s <= p.ns; s += THREADS)
-                wl[s] = s < p.ns ? slot_weight(p.fused_rates, p.slot_top, p.chain_off, p.chain_rate, s) : 0.f;
-        } else {
-            for (uint32_t s = tid; s <= p.ns; s += THREADS) wl[s] = p.wslot[s];
-        }
-    }
+    Slot sl[VPT];
+    // kMorphFused1: entries of a morph row in flight per lane (a single frame is latency-bound and has the registers)
+    constexpr uint32_t BH = MORPH == kMorphFused1 ? (F16 ? 16u : 8u) : kRowAhead;
+    RowHead<F16, BH> hd[VPT];
     // kMorphFused4: slot weights of one PACK of instances (kQuads quads of four) at a time; the first pack's are
     // requested here, under the set-up's other loads
     constexpr int kQuads = VPT == 1 ? 2 : 1, kPack = 4 * kQuads;
@@ -537,15 +632,23 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         const float4 *src = reinterpret_cast<const float4 *>(p.wslot) + size_t((inst0 + g0) / 4) * wstride;
         return (i < wstride || g0 + 4 < gcount) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    if constexpr (MORPH == kMorphFused4) {
-        float4 *wq0 = reinterpret_cast<float4 *>(smem + p.w_off);
-        for (uint32_t i = tid; i < wcount && gcount; i += THREADS) wq0[i] = pack_weight(0, i);
-    }
-
-    // 3. static per-vertex data -> registers (sorted slot s = tid + k*THREADS)
-    Slot sl[VPT];
+    if constexpr (MORPH == kMorphFused1) {
+        // palettes, slot weights (ONE set of morph rates for the whole launch; group morphs flattened in here when the raw
+        // rates are passed), static vertex data and the heads of the morph rows, in latency order
+        setup_fused1<THREADS, LAYOUT, kMorphFused1, F16, VPT, BH>(p, th, pal, reinterpret_cast<float *>(smem + p.w_off), inst0, istep,
+                                                                   gcount, tid, 0u, sl, hd);
+    } else {
+        // 1. bone palettes of the group's instances -> LDS: only the tile's bones, in the pair layout
+        stage_palettes<THREADS>(p, th, pal, inst0, istep, gcount, tid);
+        // 2. morph slot weights of the first pack -> LDS
+        if constexpr (MORPH == kMorphFused4) {
+            float4 *wq0 = reinterpret_cast<float4 *>(smem + p.w_off);
+            for (uint32_t i = tid; i < wcount && gcount; i += THREADS) wq0[i] = pack_weight(0, i);
+        }
+        // 3. static per-vertex data -> registers (sorted slot s = tid + k*THREADS)
 #pragma unroll
-    for (int k = 0; k < VPT; ++k) load_slot<LAYOUT, MORPH, F16>(p, th, uint32_t(tid) + uint32_t(k) * THREADS, sl[k]);
+        for (int k = 0; k < VPT; ++k) load_slot<LAYOUT, MORPH, F16>(p, th, uint32_t(tid) + uint32_t(k) * THREADS, sl[k]);
+    }
     __syncthreads();
 
     uint32_t buf = 0;
@@ -573,7 +676,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         for (int k = 0; k < VPT; ++k) {
             v2f dxy = v2f{0.f, 0.f};
             float dz = 0.f;
-            for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
+            row_consume<F16, BH>(p.entries, sl[k].rb, sl[k].rlen, hd[k], [&](float ox, float oy, float oz, uint32_t slot) {
                 const float w = wl[slot];
                 if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
             });
@@ -664,6 +767,73 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                 __syncthreads();
             }
         }
+    }
+}
+
+// ---- ONE frame of ONE model (ni == 1): the reference's per-frame call (main.cpp:1821) -------------------------------------
+// A single frame is a few megabytes: its run time is the latency chain of a workgroup, not bandwidth.  So, unlike the crowd
+// kernel: a workgroup is a PART of a tile (THREADS sorted slots, one per lane: config 2's 98 tiles become 392 workgroups of two
+// waves, on every CU), requests are issued in latency order (setup_fused1), and every lane stores its own vertex straight from
+// registers to its original index -- no LDS image, no second barrier; the scattered 12-byte stores of 1.2 MB merge in L2.
+// Same arithmetic, same order.
+template <int THREADS, int LAYOUT, int MORPH, bool F16>
+__global__ __launch_bounds__(THREADS) void frame_kernel(const DeformParams p) {
+    constexpr uint32_t kParts = kTileVerts / THREADS;
+    constexpr uint32_t BH = F16 ? 16u : 8u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x / kParts, part = blockIdx.x - tile * kParts;
+    const TileHdr &th = p.tiles[tile];
+    if (part * THREADS >= th.nv) return;                       // the whole workgroup: nothing of this tile left for it
+    float4 *pal = reinterpret_cast<float4 *>(smem);
+    float *wl = reinterpret_cast<float *>(smem + p.w_off);
+    Slot sl[1];
+    RowHead<F16, BH> hd[1];
+    setup_fused1<THREADS, LAYOUT, MORPH, F16, 1, BH>(p, th, pal, wl, 0u, 1u, 1u, tid, part * THREADS, sl, hd);
+    __syncthreads();
+    const Slot &q = sl[0];
+    if (!q.act) return;
+    v2f cxy = q.pxy;
+    float cz = q.pz;
+    if constexpr (MORPH == kMorphFused1) {
+        // vertex_image = 0; for each applied entry: image = image + offset*rate (poser_impl.inl:340-346); coordinate = base + image
+        v2f dxy = v2f{0.f, 0.f};
+        float dz = 0.f;
+        row_consume<F16, BH>(p.entries, q.rb, q.rlen, hd[0], [&](float ox, float oy, float oz, uint32_t slot) {
+            const float w = wl[slot];
+            if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
+        });
+        cxy = q.pxy + dxy; cz = q.pz + dz;
+        if (p.morphed) {   // kept (sorted order) for later calls that declare the rates unchanged
+            float *mo = p.morphed + (size_t(th.v0) + part * THREADS + uint32_t(tid)) * 3;
+            mo[0] = cxy.x; mo[1] = cxy.y; mo[2] = cz;
+        }
+    }
+    const M12 m = skin_matrix(q, pal);
+    v2f oxy, rxy;
+    float oz, rz;
+    xform_pos(m, cxy, cz, oxy, oz);
+    xform_nrm(m, q.nxy, q.nz, rxy, rz);
+    oxy = oxy * p.pos_scale;                                   // a separate multiply after the transform (main.cpp:848-850)
+    oz = oz * p.pos_scale;
+    const size_t v = size_t(th.v0) + q.perm;                   // original vertex index
+    if constexpr (LAYOUT == MMDX_OUT_SOA) {
+        float *A = reinterpret_cast<float *>(p.out_a) + v * 3, *B = reinterpret_cast<float *>(p.out_b) + v * 3;
+        A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
+        B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
+    } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
+        float *A = reinterpret_cast<float *>(p.out_a) + v * 8;
+        if (p.out_aligned) {
+            reinterpret_cast<float4 *>(A)[0] = make_float4(oxy.x, oxy.y, oz, rxy.x);
+            reinterpret_cast<float4 *>(A)[1] = make_float4(rxy.y, rz, q.uv.x, q.uv.y);
+        } else {
+            A[0] = oxy.x; A[1] = oxy.y; A[2] = oz; A[3] = rxy.x; A[4] = rxy.y; A[5] = rz; A[6] = q.uv.x; A[7] = q.uv.y;
+        }
+    } else {
+        unsigned short *A = reinterpret_cast<unsigned short *>(p.out_a) + v * 3;
+        float *B = reinterpret_cast<float *>(p.out_b) + v * 3;
+        A[0] = f2h(oxy.x); A[1] = f2h(oxy.y); A[2] = f2h(oz);
+        B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
     }
 }
 
@@ -814,6 +984,25 @@ KernelFn pick(int threads, int layout, int morph, bool f16) {
 
 }  // namespace
 
+namespace {
+template <int THREADS, int LAYOUT, bool F16>
+KernelFn pick_frame_morph(int morph) {
+    return morph == kMorphNone ? frame_kernel<THREADS, LAYOUT, kMorphNone, F16> : frame_kernel<THREADS, LAYOUT, kMorphFused1, F16>;
+}
+KernelFn pick_frame(int threads, int layout, int morph, bool f16) {
+    if (morph != kMorphNone && morph != kMorphFused1) return nullptr;
+    if (f16) {
+        if (layout != MMDX_OUT_SOA_POS16) return nullptr;
+        return threads == 128 ? pick_frame_morph<128, MMDX_OUT_SOA_POS16, true>(morph) : pick_frame_morph<256, MMDX_OUT_SOA_POS16, true>(morph);
+    }
+    if (layout == MMDX_OUT_SOA)
+        return threads == 128 ? pick_frame_morph<128, MMDX_OUT_SOA, false>(morph) : pick_frame_morph<256, MMDX_OUT_SOA, false>(morph);
+    if (layout == MMDX_OUT_VERTEX32)
+        return threads == 128 ? pick_frame_morph<128, MMDX_OUT_VERTEX32, false>(morph) : pick_frame_morph<256, MMDX_OUT_VERTEX32, false>(morph);
+    return nullptr;
+}
+}  // namespace
+
 size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
                         uint32_t *stage_off, uint32_t *w_off) {
     size_t off = size_t(group) * max_tile_bones * 48;
@@ -837,6 +1026,16 @@ hipError_t prepare_kernels() {
                                                    160 * 1024);
                 if (e != hipSuccess) return e;
             }
+    for (int threads = 128; threads <= 256; threads += 128)
+      for (int f16 = 0; f16 < 2; ++f16)
+        for (int layout = 0; layout < 3; ++layout)
+            for (int morph = 0; morph <= kMorphFused1; morph += kMorphFused1) {
+                KernelFn fn = pick_frame(threads, layout, morph, f16 != 0);
+                if (!fn) continue;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
     return hipSuccess;
 }
 
@@ -850,6 +1049,22 @@ hipError_t launch_deform(int threads, int layout, int morph, bool f16, const Def
     q.rem_per_xcd = ((ntiles & 7u) * q.ngroups + 7u) / 8u;
     const dim3 grid(8u * ((ntiles >> 3) * q.ngroups + q.rem_per_xcd));
     hipLaunchKernelGGL(fn, grid, dim3((threads == 256 || kTileVerts < 512) ? 256 : 512), lds_bytes, stream, q);
+    return hipGetLastError();
+}
+
+size_t frame_lds_bytes(int morph, uint32_t max_tile_bones, uint32_t ns, uint32_t *w_off) {
+    size_t off = (size_t(max_tile_bones) * 48 + 15) / 16 * 16;
+    *w_off = uint32_t(off);
+    if (morph == kMorphFused1) off += (size_t(ns + 1) * 4 + 15) / 16 * 16;
+    return off;
+}
+
+hipError_t launch_frame(int threads, int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes,
+                        hipStream_t stream) {
+    threads = threads == 128 ? 128 : 256;
+    KernelFn fn = pick_frame(threads, layout, morph, f16);
+    if (!fn) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fn, dim3(ntiles * (kTileVerts / uint32_t(threads))), dim3(threads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 

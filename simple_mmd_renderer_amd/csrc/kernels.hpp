@@ -77,6 +77,11 @@ size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint
 
 hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream);
+// One frame of one model (ni == 1, kMorphNone / kMorphFused1): latency-ordered kernel, a workgroup = `threads` (128 / 256) sorted
+// slots of a tile, direct stores.  LDS: the tile's palette, then the slot weights at *w_off.
+size_t frame_lds_bytes(int morph, uint32_t max_tile_bones, uint32_t ns, uint32_t *w_off);
+hipError_t launch_frame(int threads, int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes,
+                        hipStream_t stream);
 // `fused` != nullptr: evaluate the slot weights inside the kernel (ns <= kMaxFusedSlots), no flatten launch
 hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenParams *fused,
                               hipStream_t stream);

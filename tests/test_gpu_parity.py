@@ -808,3 +808,126 @@ def test_shared_crowd_paths_agree_and_unchanged_flag(oracle, monkeypatch, ni, fu
             b.free()
     monkeypatch.delenv("MMDX_SHARED_FUSED")
     api.lib().mmdx_debug_reload_env()
+
+
+# ---- one frame of one model: the latency-ordered frame kernel vs the tile kernel -------------------------------------
+def _one_frame_device(dm, m, rates, pal, layout, pos_scale=1.0, misalign=0):
+    """ni = 1 with every operand in device memory (the frame kernel's case); `misalign` shifts the output pointers by that
+    many bytes (4-byte multiples keep the element alignment; the 16-byte fast paths must then not be taken)."""
+    d_pal, d_w = DeviceBuffer.from_numpy(pal[None]), DeviceBuffer.from_numpy(rates[None])
+    sa, sb = dm.out_sizes(layout, 1)
+    d_a, d_b = DeviceBuffer(sa + 64), DeviceBuffer(max(sb, 16) + 64)
+    d_a.memset(0xFF); d_b.memset(0xFF)
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+    dm.deform_batched_raw(1, d_w.ptr, d_pal.ptr, d_a.ptr + misalign, (d_b.ptr + misalign) if sb else None, layout, flags, pos_scale)
+    dm.sync()
+    a = d_a.download((sa + 64,), np.uint8)[misalign:misalign + sa]
+    b = d_b.download((max(sb, 16) + 64,), np.uint8)[misalign:misalign + sb]
+    for x in (d_pal, d_w, d_a, d_b):
+        x.free()
+    return a, b
+
+
+def _with_group_morphs(m):
+    """Two group morphs on top of the model's vertex morphs: one over three of them (sub-rates incl. one that falls under the 1e-7
+    skip once multiplied), one over a vertex morph and the first group (depth 2)."""
+    nm = m.nm
+    m.morph_type = np.concatenate([m.morph_type, [MORPH_GROUP, MORPH_GROUP]]).astype(np.int32)
+    idx = list(m.morph_index) + [0, 1 % nm, 2 % nm] + [3 % nm, nm]
+    val = list(map(tuple, m.morph_value)) + [(0.5, 0, 0), (1e-4, 0, 0), (2.0, 0, 0)] + [(1.0, 0, 0), (0.75, 0, 0)]
+    m.morph_off = np.concatenate([m.morph_off, [len(idx) - 2, len(idx)]]).astype(np.uint32)
+    m.morph_index = np.asarray(idx, np.uint32)
+    m.morph_value = np.asarray(val, np.float32).reshape(-1, 3)
+    return m
+
+
+FRAME_VARIANTS = [("tile kernel", {"MMDX_FRAME_KERNEL": "0"}), ("tile kernel, 256 threads", {"MMDX_FRAME_KERNEL": "0", "MMDX_THREADS": "256"}),
+                  ("frame kernel, 128", {"MMDX_FRAME_KERNEL": "2", "MMDX_FRAME_THREADS": "128"}),
+                  ("frame kernel, 256", {"MMDX_FRAME_KERNEL": "2", "MMDX_FRAME_THREADS": "256"}), ("default", {})]
+
+
+def _with_env(monkeypatch, env):
+    for k in ("MMDX_FRAME_KERNEL", "MMDX_FRAME_THREADS", "MMDX_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    api.lib().mmdx_debug_reload_env()
+
+
+@pytest.mark.parametrize("nv", [1, 63, 129, 512, 513, 1000, 4099])
+def test_frame_kernel_every_layout_and_size(oracle, monkeypatch, nv):
+    """One frame through every single-frame route (tile kernel with 256 / 512 threads, frame kernel with 128 / 256 lanes per
+    workgroup, the default choice): SoA, the 32-byte vertex (16-byte aligned and not) and the f16-position layout, ragged
+    sizes, group morphs with rates around the 1e-7 skip -- all bit-identical to the oracle."""
+    m = _with_group_morphs(synth.make_model(nv, 40, 9, min(300, max(nv // 2, 1)), seed=9100 + nv))
+    q = m.copy()
+    q.positions = m.positions.astype(np.float16).astype(np.float32)
+    q.morph_value = m.morph_value.astype(np.float16).astype(np.float32)
+    rates = synth.morph_weights(m.nm, 23)[0]
+    rates[0] = 0.0; rates[1 % m.nm] = 5e-8; rates[2 % m.nm] = 1.0       # skipped, skipped (< 1e-7), full
+    pal = synth.make_palettes(m, 11)[0]
+    ep, en = oracle_expect(oracle, m, rates, pal)
+    ev32 = oracle.repack32(m, ep, en, 0.1)
+    ep16, en16 = oracle_expect(oracle, q, rates, pal)
+    with DeformModel(m) as dm, DeformModel(m, f16_positions=True) as dm16:
+        for what, env in FRAME_VARIANTS:
+            _with_env(monkeypatch, env)
+            a, b = _one_frame_device(dm, m, rates, pal, api.OUT_SOA)
+            assert np.array_equal(a.view(np.uint32), ep.view(np.uint32).ravel()), f"{what}: pos"
+            assert np.array_equal(b.view(np.uint32), en.view(np.uint32).ravel()), f"{what}: nrm"
+            for mis in (0, 4):
+                a, _ = _one_frame_device(dm, m, rates, pal, api.OUT_VERTEX32, 0.1, mis)
+                assert np.array_equal(a.view(np.uint32), ev32.view(np.uint32).ravel()), f"{what}: vertex32 (+{mis} B)"
+            a, b = _one_frame_device(dm16, m, rates, pal, api.OUT_SOA_POS16)
+            assert np.array_equal(a.view(np.uint16), ep16.astype(np.float16).view(np.uint16).ravel()), f"{what}: f16 pos"
+            assert np.array_equal(b.view(np.uint32), en16.view(np.uint32).ravel()), f"{what}: f16 nrm"
+    _with_env(monkeypatch, {})
+
+
+def test_frame_kernel_no_morphs_many_bones_nonfinite(oracle, monkeypatch):
+    """The frame kernel's other corners: a model without morph slots (kMorphNone), a tile that uses more than a hundred bones
+    (palette rows beyond the first batch of a 128-lane workgroup), non-finite morph offsets (skipped slots must not touch
+    them) and more slots than one batch of the weight staging (> 1024)."""
+    rng = np.random.RandomState(77)
+    cases = []
+    m0 = synth.make_model(1500, 30, 1, 1, seed=31)                              # no morphs at all
+    m0.morph_type, m0.morph_off = np.zeros(0, np.int32), np.zeros(1, np.uint32)
+    m0.morph_index, m0.morph_value = np.zeros(0, np.uint32), np.zeros((0, 3), np.float32)
+    cases.append(("no morphs", m0, np.zeros(0, np.float32)))
+    m1 = synth.make_model(700, 300, 4, 100, seed=32)
+    m1.bone_ids[:] = rng.randint(0, 300, m1.bone_ids.shape)                     # every tile touches ~all bones
+    cases.append(("many bones", m1, synth.morph_weights(m1.nm, 3)[0]))
+    m2 = synth.make_model(900, 20, 6, 200, seed=33)
+    m2.morph_value[m2.morph_off[0]:m2.morph_off[1], 0] = np.inf; m2.morph_value[m2.morph_off[2] + 1, 2] = np.nan
+    r2 = synth.morph_weights(m2.nm, 9)[0]; r2[::2] = 0.0                        # the non-finite morphs 0 and 2 are skipped
+    cases.append(("non-finite offsets", m2, r2))
+    m3 = synth.make_model(2000, 20, 1300, 3, seed=34)                           # 1300 slots
+    cases.append(("1300 slots", m3, synth.morph_weights(m3.nm, 4)[0]))
+    for name, m, rates in cases:
+        pal = synth.make_palettes(m, 5)[0]
+        ep, en = oracle_expect(oracle, m, rates, pal)
+        with DeformModel(m) as dm:
+            for what, env in FRAME_VARIANTS:
+                _with_env(monkeypatch, env)
+                a, b = _one_frame_device(dm, m, rates if rates.size else np.zeros(1, np.float32), pal, api.OUT_SOA)
+                assert np.isfinite(ep).all()
+                assert np.array_equal(a.view(np.uint32), ep.view(np.uint32).ravel()), f"{name}, {what}: pos"
+                assert np.array_equal(b.view(np.uint32), en.view(np.uint32).ravel()), f"{name}, {what}: nrm"
+    _with_env(monkeypatch, {})
+
+
+def test_config2_single_frames_device_resident(oracle, monkeypatch):
+    """BASELINE config 2, one frame per call with everything in HBM (what bench.py times as config2_single_frame): the frame
+    kernel (default for a 98-tile model) and the tile kernel, every vertex of three frames against the oracle."""
+    m = synth.make_config("config2_50k")
+    frames = [0, 17, 599]
+    rates, pals = synth.morph_weights(m.nm, frames), synth.make_palettes(m, frames)
+    with DeformModel(m) as dm:
+        for k, f in enumerate(frames):
+            ep, en = oracle_expect(oracle, m, rates[k], pals[k])
+            for what, env in (("default", {}), ("tile kernel", {"MMDX_FRAME_KERNEL": "0"})):
+                _with_env(monkeypatch, env)
+                a, b = _one_frame_device(dm, m, rates[k], pals[k], api.OUT_SOA)
+                assert np.array_equal(a.view(np.uint32), ep.view(np.uint32).ravel()), f"frame {f}, {what}: pos"
+                assert np.array_equal(b.view(np.uint32), en.view(np.uint32).ravel()), f"frame {f}, {what}: nrm"
+    _with_env(monkeypatch, {})

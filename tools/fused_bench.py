@@ -3,7 +3,7 @@
 positions), config 3' (1024-instance crowd, every instance its own morph weights).  Prints ms per call and the
 algorithmic-bytes rate; small enough to run under rocprofv3 (--kernel-trace / --pmc passes).
 
-    python tools/fused_bench.py [c2] [c5] [c3p] [--iters N]
+    python tools/fused_bench.py [c2] [c5] [c3p] [c2x1] [c5x1] [--iters N]   (c2x1 / c5x1: one frame per launch)
 """
 import os
 import sys
@@ -47,15 +47,20 @@ def run(name, model, ni, frames, layout, iters, f16=False):
 def main():
     which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c2", "c5", "c3p"]
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
-    if "c2" in which or "c3p" in which:
+    if "c2" in which or "c3p" in which or "c2x1" in which:
         m = synth.make_config("config2_50k")
         if "c2" in which:
             run("c2x64", m, 64, np.arange(64), api.OUT_SOA, iters)
+        if "c2x1" in which:
+            run("c2x1", m, 1, np.arange(1) + 17, api.OUT_SOA, iters * 10)
         if "c3p" in which:
             run("c3prime", m, 1024, (np.arange(1024) * 7) % 600, api.OUT_SOA, max(iters // 2, 5))
     if "c5" in which:
         m5 = synth.make_config("config5_256k")
         run("c5x64", m5, 64, np.arange(64), api.OUT_SOA_POS16, iters, f16=True)
+    if "c5x1" in which:
+        m5 = synth.make_config("config5_256k")
+        run("c5x1", m5, 1, np.arange(1) + 17, api.OUT_SOA_POS16, iters * 10, f16=True)
 
 
 if __name__ == "__main__":
