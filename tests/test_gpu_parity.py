@@ -931,3 +931,78 @@ def test_config2_single_frames_device_resident(oracle, monkeypatch):
                 assert np.array_equal(a.view(np.uint32), ep.view(np.uint32).ravel()), f"frame {f}, {what}: pos"
                 assert np.array_equal(b.view(np.uint32), en.view(np.uint32).ravel()), f"frame {f}, {what}: nrm"
     _with_env(monkeypatch, {})
+
+
+# ---- per-instance morph weights with everything in HBM ------------------------------------------------------------------
+def _batch_device(dm, rates, pals, layout, pos_scale=1.0, misalign=0):
+    ni = pals.shape[0]
+    d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
+    sa, sb = dm.out_sizes(layout, ni)
+    d_a, d_b = DeviceBuffer(sa + 64), DeviceBuffer(max(sb, 16) + 64)
+    d_a.memset(0xFF); d_b.memset(0xFF)
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+    dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr + misalign, (d_b.ptr + misalign) if sb else None, layout, flags, pos_scale)
+    dm.sync()
+    a = d_a.download((sa + 64,), np.uint8)[misalign:misalign + sa]
+    b = d_b.download((max(sb, 16) + 64,), np.uint8)[misalign:misalign + sb]
+    for x in (d_pal, d_w, d_a, d_b):
+        x.free()
+    return a, b
+
+
+@pytest.mark.parametrize("nv,ni", [(1, 2), (63, 5), (300, 8), (513, 9), (1000, 13), (4099, 17), (2600, 33)])
+def test_per_instance_morphs_device_resident_every_layout_and_size(oracle, nv, ni):
+    """Per-instance morph weights, device-resident operands (the form bench.py times): ragged vertex counts and pack counts
+    (partial last quad and pack of 8), group morphs with rates around the 1e-7 skip, SoA / 32-byte vertex (16-byte aligned and
+    not) / f16 positions: bit-identical to the oracle."""
+    m = _with_group_morphs(synth.make_model(nv, 40, 9, min(300, max(nv // 2, 1)), seed=9300 + nv))
+    q = m.copy()
+    q.positions = m.positions.astype(np.float16).astype(np.float32)
+    q.morph_value = m.morph_value.astype(np.float16).astype(np.float32)
+    rates = synth.morph_weights(m.nm, np.arange(ni) * 7 + 3)
+    rates[:, 0] = np.where(np.arange(ni) % 3 == 0, 0.0, rates[:, 0])
+    rates[:, 1 % m.nm] = np.where(np.arange(ni) % 2 == 0, 5e-8, 1.0)
+    pals = synth.make_palettes(m, np.arange(ni) * 5)
+    exp = [oracle_expect(oracle, m, rates[i], pals[i]) for i in range(ni)]
+    exp16 = [oracle_expect(oracle, q, rates[i], pals[i]) for i in range(ni)]
+    ep = np.stack([e[0] for e in exp]); en = np.stack([e[1] for e in exp])
+    ev32 = np.stack([oracle.repack32(m, e[0], e[1], 0.1) for e in exp])
+    ep16 = np.stack([e[0] for e in exp16]).astype(np.float16); en16 = np.stack([e[1] for e in exp16])
+    with DeformModel(m) as dm, DeformModel(m, f16_positions=True) as dm16:
+        for what in ("tile kernel",):
+            a, b = _batch_device(dm, rates, pals, api.OUT_SOA)
+            assert np.array_equal(a.view(np.uint32), ep.view(np.uint32).ravel()), f"{what}: pos"
+            assert np.array_equal(b.view(np.uint32), en.view(np.uint32).ravel()), f"{what}: nrm"
+            for mis in (0, 4):
+                a, _ = _batch_device(dm, rates, pals, api.OUT_VERTEX32, 0.1, mis)
+                assert np.array_equal(a.view(np.uint32), ev32.view(np.uint32).ravel()), f"{what}: vertex32 (+{mis} B)"
+            a, b = _batch_device(dm16, rates, pals, api.OUT_SOA_POS16)
+            assert np.array_equal(a.view(np.uint16), ep16.view(np.uint16).ravel()), f"{what}: f16 pos"
+            assert np.array_equal(b.view(np.uint32), en16.view(np.uint32).ravel()), f"{what}: f16 nrm"
+
+
+def test_per_instance_morphs_device_resident_corners(oracle):
+    """Device-resident per-instance morphs: tiles that use hundreds of bones, non-finite morph offsets (the predicated skip),
+    1 300 slots."""
+    rng = np.random.RandomState(78)
+    ni = 11
+    cases = []
+    m1 = synth.make_model(700, 300, 4, 100, seed=42)
+    m1.bone_ids[:] = rng.randint(0, 300, m1.bone_ids.shape)
+    cases.append(("many bones", m1, synth.morph_weights(m1.nm, np.arange(ni))))
+    m2 = synth.make_model(900, 20, 6, 200, seed=43)
+    m2.morph_value[m2.morph_off[0]:m2.morph_off[1], 0] = np.inf; m2.morph_value[m2.morph_off[2] + 1, 2] = np.nan
+    r2 = synth.morph_weights(m2.nm, np.arange(ni) * 3); r2[:, ::2] = 0.0
+    cases.append(("non-finite offsets", m2, r2))
+    m3 = synth.make_model(2000, 20, 1300, 3, seed=44)
+    cases.append(("1300 slots", m3, synth.morph_weights(m3.nm, np.arange(ni) * 2)))
+    for name, m, rates in cases:
+        pals = synth.make_palettes(m, np.arange(ni) * 4)
+        with DeformModel(m) as dm:
+            a, b = _batch_device(dm, rates, pals, api.OUT_SOA)
+            pos, nrm = a.view(np.float32).reshape(ni, m.nv, 3), b.view(np.float32).reshape(ni, m.nv, 3)
+            for i in range(ni):
+                ep, en = oracle_expect(oracle, m, rates[i], pals[i])
+                assert np.isfinite(ep).all()
+                gu.assert_bits_equal(pos[i], ep, f"{name} inst {i} pos")
+                gu.assert_bits_equal(nrm[i], en, f"{name} inst {i} nrm")
