@@ -254,6 +254,12 @@ def test_randomized_models_all_call_forms(oracle, seed):
         ep, en = oracle.skin(m, pals[ni - 1], oracle.morph(m, rates[ni - 1]), skin)
         gu.assert_bits_equal(p1, ep, "single pos")
         gu.assert_bits_equal(n1, en, "single nrm")
+        # the same frame with every operand in device memory (the frame kernel's route)
+        a, b = _one_frame_device(dm, m, rates[ni - 1] if m.nm else np.zeros(1, np.float32), pals[ni - 1], api.OUT_SOA)
+        assert np.array_equal(a.view(np.uint32), ep.view(np.uint32).ravel()), f"seed {seed} device-resident frame pos"
+        assert np.array_equal(b.view(np.uint32), en.view(np.uint32).ravel()), f"seed {seed} device-resident frame nrm"
+        a, _ = _one_frame_device(dm, m, rates[ni - 1] if m.nm else np.zeros(1, np.float32), pals[ni - 1], api.OUT_VERTEX32, 0.1)
+        assert np.array_equal(a.view(np.uint32), oracle.repack32(m, ep, en, 0.1).view(np.uint32).ravel()), f"seed {seed} device-resident v32"
 
 
 def test_device_resident_io_matches_host_io(oracle):
