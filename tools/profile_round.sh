@@ -4,7 +4,7 @@
 # 1. plain bench line; 2. rocprofv3 --kernel-trace --stats of the same command; 3./4. separate PMC passes (FETCH_SIZE,
 # WRITE_SIZE) as the microarchitecture guide prescribes; 5. SQ counter passes of the crowd step; 6. a trace with the
 # secondary workloads on (all kernels of the library); 7. the per-instance-morph workloads alone (trace + PMC passes);
-# 8. SQ counters of the rig kernels.  Outputs in gpurun_out/<tag>/; tools/summarize_profiles.py condenses them.
+# 8. SQ counters of the rig kernels; 9. the single-frame kernels (trace + SQ counters).  Outputs in gpurun_out/<tag>/; tools/summarize_profiles.py condenses them.
 # rocprofv3 is always given the program itself after "--" (python3 ...), never a wrapper.
 set -e -o pipefail
 tag=${1:-r02}
@@ -40,4 +40,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/rig_kt -o kt -- $R 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --kernel-trace --output-format csv -d $out/rig_sq1 -o sq1 -- $R > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 --kernel-trace --output-format csv -d $out/rig_sq2 -o sq2 -- $R > /dev/null 2>&1 || true
 echo "rig passes done" >&2
+# 9. one frame of one model per launch (frame kernel for config 2, 512-thread tile kernel for config 5): trace + SQ counters
+S="python3 tools/fused_bench.py c2x1 c5x1 --iters 50"
+$S > $out/frame_plain.txt
+MMDX_FRAME_KERNEL=0 MMDX_THREADS=256 $S > $out/frame_plain_round1_path.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/frame_kt -o kt -- $S > /dev/null 2> $out/frame_rocprof.log
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $out/frame_sq1 -o sq1 -- $S > /dev/null 2>&1 || true
+echo "single-frame passes done" >&2
 find $out -name "*.csv" | wc -l

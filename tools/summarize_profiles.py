@@ -100,8 +100,11 @@ def extras(src, dst):
     counter_summary(src, ["fused_fetch", "fused_write", "fused_sq1", "fused_sq2", "fused_tcc"],
                     os.path.join(dst, "fused_gather_pmc.csv"), ["deform_kernel", "flatten"])
     counter_summary(src, ["rig_sq1", "rig_sq2"], os.path.join(dst, "rig_pmc_sq.csv"), ["skeleton", "bone_track"])
+    counter_summary(src, ["frame_sq1"], os.path.join(dst, "single_frame_pmc_sq.csv"), ["frame_kernel", "deform_kernel"])
     for a, b in (("fused_kt/kt_kernel_stats.csv", "fused_gather_kernel_stats.csv"), ("fused_plain.txt", "fused_gather_bench.txt"),
-                 ("rig_kt/kt_kernel_stats.csv", "rig_kernel_stats.csv"), ("rig_plain.txt", "rig_bench.txt")):
+                 ("rig_kt/kt_kernel_stats.csv", "rig_kernel_stats.csv"), ("rig_plain.txt", "rig_bench.txt"),
+                 ("frame_kt/kt_kernel_stats.csv", "single_frame_kernel_stats.csv"), ("frame_plain.txt", "single_frame_bench.txt"),
+                 ("frame_plain_round1_path.txt", "single_frame_bench_round1_path.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 
