@@ -439,7 +439,7 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     b64 = static + table + nfr * (model3.nv * 24 + model3.nb * 48 + model3.nm * 4)
     out["config2_single_frame"] = {"ms_per_call": ms1, "vertices_per_s": model3.nv / (ms1 * 1e-3),
                                    "algorithmic_GBs": b1 / (ms1 * 1e-3) / 1e9,
-                                   "note": "one 50k-vert frame per launch: launch-latency bound"}
+                                   "note": "one 50k-vert frame per launch (frame kernel): bound by the latency chain of one workgroup, not by bandwidth"}
     out["config2_64_frames_per_launch"] = {"ms_per_call": ms64,
                                            "vertices_per_s": nfr * model3.nv / (ms64 * 1e-3),
                                            "algorithmic_GBs": b64 / (ms64 * 1e-3) / 1e9,
