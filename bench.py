@@ -548,6 +548,39 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     except Exception as e:                                   # pragma: no cover - reporting only
         out["config3prime_per_instance_morphs"] = {"error": repr(e)}
 
+    # OPT-IN, NOT the headline and NOT bit-exact: the same workloads on a model created with MMDX_CREATE_FAST_MATH (multiply-adds
+    # contracted; results within the tolerance stated in include/mmdx.h, tests/test_fast_math.py).  What the bit-exact contract costs.
+    try:
+        ni = 1024
+        dmf = DeformModel(model3, fast_math=True)
+        fr_i = (np.arange(ni) * 7) % 600
+        d_wi = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, fr_i))
+        d_pali = DeviceBuffer.from_numpy(synth.make_palettes(model3, fr_i))
+        d_ws = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, 30)[0])
+        d_af, d_bf, _pl = dmf.alloc_outputs(api.OUT_SOA, ni, 32)
+        shared = flags_dev | api.WEIGHTS_SHARED
+        ms_step = time_calls(dmf, lambda: dmf.deform_batched_raw(ni, d_ws.ptr, d_pali.ptr, d_af.ptr, d_bf.ptr, api.OUT_SOA, shared), 20)
+        ms_k = time_calls(dmf, lambda: dmf.deform_batched_raw(ni, d_ws.ptr, d_pali.ptr, d_af.ptr, d_bf.ptr, api.OUT_SOA,
+                                                              shared | api.MORPH_UNCHANGED), 20)
+        ms_i = time_calls(dmf, lambda: dmf.deform_batched_raw(ni, d_wi.ptr, d_pali.ptr, d_af.ptr, d_bf.ptr, api.OUT_SOA, flags_dev), 10)
+        ms_64 = time_calls(dmf, lambda: dmf.deform_batched_raw(64, d_wi.ptr, d_pali.ptr, d_af.ptr, d_bf.ptr, api.OUT_SOA, flags_dev), 50)
+        kbytes, _sb = algorithmic_bytes_config3(model3.nv, model3.nb, model3.nm, i.n_entries, ni, i.n_bdef1, i.n_bdef2, i.n_bdef4)
+        bi = static + table + ni * (model3.nv * 24 + model3.nb * 48 + model3.nm * 4)
+        b64f = static + table + 64 * (model3.nv * 24 + model3.nb * 48 + model3.nm * 4)
+        out["fast_math_opt_in"] = {
+            "note": "MMDX_CREATE_FAST_MATH: contracted multiply-adds, within the stated tolerance of the reference, NOT bit-exact; "
+                    "the default (everything else in this line) is bit-exact",
+            "config3_ms_per_step": ms_step, "config3_vertices_per_s": ni * model3.nv / (ms_step * 1e-3),
+            "config3_deform_kernel_ms": ms_k, "config3_deform_kernel_frac_of_8TBs": kbytes / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "config3prime_ms_per_call": ms_i, "config3prime_frac_of_8TBs": bi / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "config2_64_frames_ms_per_call": ms_64, "config2_64_frames_frac_of_8TBs": b64f / (ms_64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "placement": _pl}
+        for b in (d_wi, d_pali, d_ws, d_af, d_bf):
+            b.free()
+        dmf.close()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["fast_math_opt_in"] = {"error": repr(e)}
+
     # The palette producer for the crowd: a 300-track bone motion with Bezier curves
     # -> local poses -> FK palettes for 1024 instances at their own frames, all in HBM; then the whole
     # motion -> vertices step (poses + palettes + morph pass + deform).  CPU: libmmd doing the same bone

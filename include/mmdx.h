@@ -79,9 +79,19 @@ enum {
     MMDX_CREATE_NORMALIZE = 1u << 0, /* apply Model::Normalize retagging (needs bone_parent)        */
     MMDX_CREATE_HOST_ONLY = 1u << 1, /* build + validate the plan only; touch no device (for tests
                                         and tools on machines without a GPU; deform then fails)     */
-    MMDX_CREATE_F16_POSITIONS = 1u << 2 /* keep base positions and morph offsets as IEEE binary16 in
+    MMDX_CREATE_F16_POSITIONS = 1u << 2, /* keep base positions and morph offsets as IEEE binary16 in
                                         HBM (rounded to nearest even once, here); arithmetic stays
                                         f32.  Bandwidth-stress configuration, not reference parity */
+    MMDX_CREATE_FAST_MATH = 1u << 3  /* OPT-IN: the deform kernels of this model may contract a multiply and the add
+                                        that consumes it into one fused multiply-add (one rounding instead of two), as
+                                        any compiler does to L/motion/poser_impl.inl:396-437 at -ffp-contract=fast.
+                                        Same operations in the same order, same epsilon tests and morph skips; results
+                                        are then NOT bit-identical to libmmd's but within the tolerance stated and
+                                        tested in tests/test_fast_math.py: |x - x_ref| <= 1e-5 * (1 + |x_ref|) per
+                                        position component (measured on the benchmark models: 2.4e-6, a handful of
+                                        binary32 ulps), <= 2e-6 per normal component (measured 1.8e-7), binary16
+                                        positions within that plus one binary16 ulp.  Buys 5-8 % throughput.
+                                        Without this flag (the default) every result is bit-identical to the reference's. */
 };
 
 /* Flat model description.  All pointers are host pointers, borrowed for the duration of the call. */

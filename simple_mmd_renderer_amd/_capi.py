@@ -15,7 +15,7 @@ OK = 0
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5: "OUT_OF_MEMORY",
              6: "UNSUPPORTED"}
 
-CREATE_NORMALIZE, CREATE_HOST_ONLY, CREATE_F16_POSITIONS = 1, 2, 4
+CREATE_NORMALIZE, CREATE_HOST_ONLY, CREATE_F16_POSITIONS, CREATE_FAST_MATH = 1, 2, 4, 8
 OUT_SOA, OUT_VERTEX32, OUT_SOA_POS16 = 0, 1, 2
 PALETTE_ON_DEVICE, WEIGHTS_ON_DEVICE, OUT_ON_DEVICE, WEIGHTS_SHARED, MORPH_UNCHANGED = 1, 2, 4, 8, 16
 

@@ -2,7 +2,8 @@
 
     python -m simple_mmd_renderer_amd.build [--force]
 
-One explicit hipcc command, no build system: the product is three translation units.  The .so is
+One explicit hipcc command, no build system: the product is a dozen translation units (kernels_fast.hip is kernels.hip
+compiled a second time with multiply-add contraction allowed, for models created with MMDX_CREATE_FAST_MATH).  The .so is
 git-ignored but travels to the GPU box with the working tree.  -ffp-contract=off is part of the
 contract (bit-exact parity with the reference's CPU arithmetic), not a debug flag.
 """
@@ -16,7 +17,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdx.so")
-SOURCES = ["api.cpp", "kernels.hip", "plan.cpp", "pmx.cpp", "pmd.cpp", "vmd.cpp", "error.cpp",
+SOURCES = ["api.cpp", "kernels.hip", "kernels_fast.hip", "plan.cpp", "pmx.cpp", "pmd.cpp", "vmd.cpp", "error.cpp",
            "rig.cpp", "rig_api.cpp", "rig_kernels.hip"]
 HEADERS = ["kernels.hpp", "plan.hpp", "error.hpp", "vmd.hpp", "rig.hpp", "rig_kernels.hpp", "pmx.hpp", os.path.join("..", "..", "include", "mmdx.h")]
 ARCH = "gfx950"

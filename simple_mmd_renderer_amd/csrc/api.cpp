@@ -360,7 +360,10 @@ mmdx_status mmdx_model_create(const mmdx_model_desc *desc, mmdx_model_t *out_mod
     m->device = current_device();
     auto bail = [&](mmdx_status s) { free_model(m); return s; };
     if ((e = hipSetDevice(m->device)) != hipSuccess) return bail(hip_fail(e, "hipSetDevice"));
-    std::call_once(g_prepare_once[m->device], [&] { g_prepare_status[m->device] = prepare_kernels(); });
+    std::call_once(g_prepare_once[m->device], [&] {
+        hipError_t pe = prepare_kernels();
+        g_prepare_status[m->device] = pe != hipSuccess ? pe : prepare_kernels_fast();
+    });
     if (g_prepare_status[m->device] != hipSuccess)
         return bail(hip_fail(g_prepare_status[m->device], "hipFuncSetAttribute(dynamic LDS)"));
     if ((e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess)
@@ -464,6 +467,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (m->profile) return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_profile_enable and graph recording exclude each other");
     }
     const bool shared = (a->flags & MMDX_WEIGHTS_SHARED) != 0 || ni == 1;
+    const bool fast = (p.flags & MMDX_CREATE_FAST_MATH) != 0;      // contracted multiply-adds: this model opted out of bit-exactness
     const uint64_t nvi = uint64_t(ni) * p.nv;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = m->stream;
@@ -550,14 +554,14 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (morph == kMorphShared && unchanged) {
             // nothing to launch: `morphed` holds the positions
         } else if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
-            HIP_TRY(launch_morph_apply(p.f16, dp, &f, st));      // flatten fused in: one launch
+            HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, &f, st));      // flatten fused in: one launch
         } else if (morph == kMorphFused1) {
             dp.fused_rates = rates_dev;                           // flatten inside the deform kernel
             dp.slot_top = f.slot_top; dp.chain_off = f.chain_off; dp.chain_rate = f.chain_rate;
             dp.nm = p.nm;
         } else {
             HIP_TRY(launch_flatten(f, st));
-            if (morph == kMorphShared) HIP_TRY(launch_morph_apply(p.f16, dp, nullptr, st));
+            if (morph == kMorphShared) HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, nullptr, st));
         }
         if (pev) HIP_TRY(hipEventRecord(pev[3], st));
         if (morph == kMorphShared || (morph == kMorphFused1 && ni > 1)) m->morphed_valid = true;   // kept by either path
@@ -658,9 +662,9 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         const size_t flds = frame_lds_bytes(morph, p.max_tile_bones, p.ns, &fp.w_off);
         if (flds > 160 * 1024)
             return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(flds) + " bytes of LDS (> 160 KiB)");
-        HIP_TRY(launch_frame(ov.frame_threads, int(layout), morph, p.f16, fp, p.ntiles, flds, st));
+        HIP_TRY((fast ? launch_frame_fast : launch_frame)(ov.frame_threads, int(layout), morph, p.f16, fp, p.ntiles, flds, st));
     } else {
-        HIP_TRY(launch_deform(threads, int(layout), morph, p.f16, dp, p.ntiles, lds, st));
+        HIP_TRY((fast ? launch_deform_fast : launch_deform)(threads, int(layout), morph, p.f16, dp, p.ntiles, lds, st));
     }
     if (pev) {
         HIP_TRY(hipEventRecord(pev[1], st));

@@ -22,6 +22,17 @@
 //   mat x vec, <= 3 flop/B).
 #include "kernels.hpp"
 
+// MMDX_FAST_MATH (kernels_fast.hip includes this file with it defined): the SAME kernels with multiply-add contraction allowed
+// (v_fma_f32 / v_pk_fma_f32) for models created with MMDX_CREATE_FAST_MATH -- results within a stated tolerance of the
+// reference's instead of bit-identical (include/mmdx.h).  Only the deform / frame / shared-morph kernels exist in that build,
+// under *_fast launch names; everything else in this file is compiled once, uncontracted.
+#ifdef MMDX_FAST_MATH
+#pragma clang fp contract(fast)
+#define MMDX_K(name) name##_fast
+#else
+#define MMDX_K(name) name
+#endif
+
 namespace mmdx {
 namespace {
 
@@ -875,6 +886,7 @@ __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParam
     p.morphed[gs * 3 + 2] = bz + dz;
 }
 
+#ifndef MMDX_FAST_MATH
 // ---- group-morph flattening on the device (UpdateMorphTransform's recursion, per slot) ------------
 __global__ __launch_bounds__(kThreads) void flatten_kernel(const FlattenParams f) {
     // output rows have ns+1 columns: column ns is the padding slot of the morph table, always 0
@@ -955,6 +967,8 @@ __global__ __launch_bounds__(kThreads) void pattern_fill_kernel(float4 *a, float
     }
 }
 
+#endif  // !MMDX_FAST_MATH
+
 using KernelFn = void (*)(const DeformParams);
 
 template <int THREADS, int LAYOUT, bool F16>
@@ -1003,6 +1017,7 @@ KernelFn pick_frame(int threads, int layout, int morph, bool f16) {
 }
 }  // namespace
 
+#ifndef MMDX_FAST_MATH
 size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
                         uint32_t *stage_off, uint32_t *w_off) {
     size_t off = size_t(group) * max_tile_bones * 48;
@@ -1014,7 +1029,9 @@ size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint
     return off;
 }
 
-hipError_t prepare_kernels() {
+#endif  // !MMDX_FAST_MATH
+
+hipError_t MMDX_K(prepare_kernels)() {
     for (int threads = 256; threads <= 512; threads += 256)
       for (int f16 = 0; f16 < 2; ++f16)
         for (int layout = 0; layout < 3; ++layout)
@@ -1039,7 +1056,7 @@ hipError_t prepare_kernels() {
     return hipSuccess;
 }
 
-hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
+hipError_t MMDX_K(launch_deform)(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream) {
     KernelFn fn = pick(threads, layout, morph, f16);
     if (!fn) return hipErrorInvalidValue;
@@ -1052,6 +1069,7 @@ hipError_t launch_deform(int threads, int layout, int morph, bool f16, const Def
     return hipGetLastError();
 }
 
+#ifndef MMDX_FAST_MATH
 size_t frame_lds_bytes(int morph, uint32_t max_tile_bones, uint32_t ns, uint32_t *w_off) {
     size_t off = (size_t(max_tile_bones) * 48 + 15) / 16 * 16;
     *w_off = uint32_t(off);
@@ -1059,7 +1077,9 @@ size_t frame_lds_bytes(int morph, uint32_t max_tile_bones, uint32_t ns, uint32_t
     return off;
 }
 
-hipError_t launch_frame(int threads, int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes,
+#endif  // !MMDX_FAST_MATH
+
+hipError_t MMDX_K(launch_frame)(int threads, int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes,
                         hipStream_t stream) {
     threads = threads == 128 ? 128 : 256;
     KernelFn fn = pick_frame(threads, layout, morph, f16);
@@ -1068,7 +1088,7 @@ hipError_t launch_frame(int threads, int layout, int morph, bool f16, const Defo
     return hipGetLastError();
 }
 
-hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenParams *fused,
+hipError_t MMDX_K(launch_morph_apply)(bool f16, const DeformParams &p, const FlattenParams *fused,
                               hipStream_t stream) {
     const dim3 grid((p.nv + kThreads - 1) / kThreads);
     if (fused) {
@@ -1083,6 +1103,7 @@ hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenPara
     return hipGetLastError();
 }
 
+#ifndef MMDX_FAST_MATH
 hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, uint32_t bpva, uint32_t bpvb,
                                hipStream_t stream) {
     const uint32_t ntiles = (nv + kTileVerts - 1) / kTileVerts;
@@ -1120,5 +1141,7 @@ hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
                        dim3(kThreads), 0, stream, reinterpret_cast<float4 *>(dst), bytes / 16);
     return hipGetLastError();
 }
+
+#endif  // !MMDX_FAST_MATH
 
 }  // namespace mmdx

@@ -93,5 +93,12 @@ hipError_t launch_morph_track_eval(const MorphTrackParams &t, hipStream_t stream
 hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream);
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
 hipError_t prepare_kernels();  // raise the dynamic-LDS limit of every deform variant (once)
+// kernels_fast.hip: the same kernels with multiply-add contraction allowed (MMDX_CREATE_FAST_MATH models)
+hipError_t launch_deform_fast(int threads, int layout, int morph, bool f16, const DeformParams &p,
+                              uint32_t ntiles, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_frame_fast(int threads, int layout, int morph, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes,
+                             hipStream_t stream);
+hipError_t launch_morph_apply_fast(bool f16, const DeformParams &p, const FlattenParams *fused, hipStream_t stream);
+hipError_t prepare_kernels_fast();
 
 }  // namespace mmdx

@@ -142,7 +142,9 @@ class DeformModel:
     """mmdx_model_t: the model compiled to the kernels' HBM layout, resident on one GPU."""
 
     def __init__(self, flat: FlatModel, normalize: bool = True, f16_positions: bool = False,
-                 host_only: bool = False):
+                 host_only: bool = False, fast_math: bool = False):
+        """fast_math: MMDX_CREATE_FAST_MATH -- contracted multiply-adds, results within the stated tolerance of the
+        reference's instead of bit-identical (include/mmdx.h)."""
         self.flat = flat
         self.f16 = bool(f16_positions)
         self._keep = dict(
@@ -158,7 +160,8 @@ class DeformModel:
         d.struct_size = C.sizeof(api.ModelDesc)
         d.flags = ((api.CREATE_NORMALIZE if normalize else 0) |
                    (api.CREATE_F16_POSITIONS if f16_positions else 0) |
-                   (api.CREATE_HOST_ONLY if host_only else 0))
+                   (api.CREATE_HOST_ONLY if host_only else 0) |
+                   (api.CREATE_FAST_MATH if fast_math else 0))
         d.n_vertices, d.n_bones, d.n_morphs = flat.nv, flat.nb, flat.nm
         d.positions = _ptr(k["positions"], _f32p)
         d.normals = _ptr(k["normals"], _f32p)
