@@ -581,6 +581,43 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
     except Exception as e:                                   # pragma: no cover - reporting only
         out["fast_math_opt_in"] = {"error": repr(e)}
 
+    # OPT-IN, NOT the headline: MMDX_CREATE_TILE_ORDER -- the same values, written in the engine's vertex order (the renderer remaps
+    # its index buffer once): no LDS image, no per-instance barrier.  Bit-exact modulo the permutation (tests/test_tile_order.py).
+    # Measured on ONE pair of output arrays against the default model, interleaved; and together with the fast-math opt-in.
+    try:
+        ni = 1024
+        d_pali = DeviceBuffer.from_numpy(synth.make_palettes(model3, (np.arange(ni) * 3) % 1801))
+        d_ws = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, 30)[0])
+        d_wi = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, (np.arange(ni) * 7) % 600))
+        d_at, d_bt, _pl = dm3.alloc_outputs(api.OUT_SOA, ni, 32)
+        shared = flags_dev | api.WEIGHTS_SHARED
+        res = {}
+        for name, kw in (("default", None), ("tile_order", dict(tile_order=True)), ("tile_order_fast_math", dict(tile_order=True, fast_math=True))):
+            dmx = dm3 if kw is None else DeformModel(model3, **kw)
+            t_step = time_calls(dmx, lambda: dmx.deform_batched_raw(ni, d_ws.ptr, d_pali.ptr, d_at.ptr, d_bt.ptr, api.OUT_SOA, shared), 20)
+            t_k = time_calls(dmx, lambda: dmx.deform_batched_raw(ni, d_ws.ptr, d_pali.ptr, d_at.ptr, d_bt.ptr, api.OUT_SOA,
+                                                                 shared | api.MORPH_UNCHANGED), 20)
+            t_i = time_calls(dmx, lambda: dmx.deform_batched_raw(ni, d_wi.ptr, d_pali.ptr, d_at.ptr, d_bt.ptr, api.OUT_SOA, flags_dev), 10)
+            res[name] = (t_step, t_k, t_i)
+            if kw is not None:
+                dmx.close()
+        kbytes, _sb = algorithmic_bytes_config3(model3.nv, model3.nb, model3.nm, i.n_entries, ni, i.n_bdef1, i.n_bdef2, i.n_bdef4)
+        bi = static + table + ni * (model3.nv * 24 + model3.nb * 48 + model3.nm * 4)
+        out["tile_order_opt_in"] = {
+            "note": "MMDX_CREATE_TILE_ORDER: same values in the engine's vertex order (index buffer remapped once by the caller); measured "
+                    "interleaved with the default model on the same output arrays; into plainly allocated arrays in the slow store mode "
+                    "it can be SLOWER than the default (DESIGN.md 6.1)",
+            "placement": _pl}
+        for name, (t_step, t_k, t_i) in res.items():
+            out["tile_order_opt_in"][name] = {"config3_ms_per_step": t_step, "config3_deform_kernel_ms": t_k,
+                                              "config3_deform_kernel_frac_of_8TBs": kbytes / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "config3prime_ms_per_call": t_i,
+                                              "config3prime_frac_of_8TBs": bi / (t_i * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        for b in (d_pali, d_ws, d_wi, d_at, d_bt):
+            b.free()
+    except Exception as e:                                   # pragma: no cover - reporting only
+        out["tile_order_opt_in"] = {"error": repr(e)}
+
     # The palette producer for the crowd: a 300-track bone motion with Bezier curves
     # -> local poses -> FK palettes for 1024 instances at their own frames, all in HBM; then the whole
     # motion -> vertices step (poses + palettes + morph pass + deform).  CPU: libmmd doing the same bone

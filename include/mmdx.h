@@ -82,7 +82,7 @@ enum {
     MMDX_CREATE_F16_POSITIONS = 1u << 2, /* keep base positions and morph offsets as IEEE binary16 in
                                         HBM (rounded to nearest even once, here); arithmetic stays
                                         f32.  Bandwidth-stress configuration, not reference parity */
-    MMDX_CREATE_FAST_MATH = 1u << 3  /* OPT-IN: the deform kernels of this model may contract a multiply and the add
+    MMDX_CREATE_FAST_MATH = 1u << 3, /* OPT-IN: the deform kernels of this model may contract a multiply and the add
                                         that consumes it into one fused multiply-add (one rounding instead of two), as
                                         any compiler does to L/motion/poser_impl.inl:396-437 at -ffp-contract=fast.
                                         Same operations in the same order, same epsilon tests and morph skips; results
@@ -92,6 +92,15 @@ enum {
                                         binary32 ulps), <= 2e-6 per normal component (measured 1.8e-7), binary16
                                         positions within that plus one binary16 ulp.  Buys 5-8 % throughput.
                                         Without this flag (the default) every result is bit-identical to the reference's. */
+    MMDX_CREATE_TILE_ORDER = 1u << 4 /* OPT-IN: every output array of this model (pose_image SoA, the 32-byte vertex, the
+                                        f16 layout) holds the vertices in the ENGINE's order instead of the file's: inside
+                                        each run of 512 consecutive file vertices they are sorted by deform class and
+                                        morph-row length (mmdx_model_get_vertex_order returns the permutation).  Values
+                                        are bit-identical to the default's, only their position in the array changes.
+                                        The kernels then store straight from registers -- no on-chip transpose, no
+                                        per-instance barrier: 8-13 % more throughput for crowds and batches.  A renderer
+                                        adopts it by remapping its index buffer once at load (main.cpp:781-787:
+                                        index[i] = original_to_engine[index[i]]); INTEGRATION.md 1d''.                  */
 };
 
 /* Flat model description.  All pointers are host pointers, borrowed for the duration of the call. */
@@ -186,6 +195,12 @@ MMDX_API mmdx_status mmdx_model_get_info(mmdx_model_t model, mmdx_model_info *in
 /* Post-Normalize skin tags in ORIGINAL vertex order: type[NV] (0,1,2), ids[NV][4], weights[NV][4]. */
 MMDX_API mmdx_status mmdx_model_get_skin(mmdx_model_t model, int32_t *type, int32_t *ids,
                                          float *weights);
+/* The engine's vertex order (a permutation of [0, NV) that only moves vertices inside their tile of 512 consecutive file
+ * vertices): engine_to_original[e] = file index of the vertex at position e of an MMDX_CREATE_TILE_ORDER model's outputs,
+ * original_to_engine = its inverse (what an index buffer is remapped through).  Either pointer may be NULL.  Defined for every
+ * model; only MMDX_CREATE_TILE_ORDER models write their outputs in this order. */
+MMDX_API mmdx_status mmdx_model_get_vertex_order(mmdx_model_t model, uint32_t *engine_to_original /*[NV]*/,
+                                                 uint32_t *original_to_engine /*[NV]*/);
 /* Host-side flattening of group morphs: slot_weights[n_slots] for one set of morph rates, exactly
  * what the device consumes (a slot whose chain hits the reference's `rate < 1e-7` skip gets 0). */
 MMDX_API mmdx_status mmdx_model_slot_weights(mmdx_model_t model, const float *morph_weights,

@@ -15,7 +15,7 @@ OK = 0
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5: "OUT_OF_MEMORY",
              6: "UNSUPPORTED"}
 
-CREATE_NORMALIZE, CREATE_HOST_ONLY, CREATE_F16_POSITIONS, CREATE_FAST_MATH = 1, 2, 4, 8
+CREATE_NORMALIZE, CREATE_HOST_ONLY, CREATE_F16_POSITIONS, CREATE_FAST_MATH, CREATE_TILE_ORDER = 1, 2, 4, 8, 16
 OUT_SOA, OUT_VERTEX32, OUT_SOA_POS16 = 0, 1, 2
 PALETTE_ON_DEVICE, WEIGHTS_ON_DEVICE, OUT_ON_DEVICE, WEIGHTS_SHARED, MORPH_UNCHANGED = 1, 2, 4, 8, 16
 
@@ -71,6 +71,7 @@ SIGNATURES = {
     "mmdx_model_destroy": (C.c_int32, [C.c_void_p]),
     "mmdx_model_get_info": (C.c_int32, [C.c_void_p, C.POINTER(ModelInfo)]),
     "mmdx_model_get_skin": (C.c_int32, [C.c_void_p, _i32p, _i32p, _f32p]),
+    "mmdx_model_get_vertex_order": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mmdx_model_slot_weights": (C.c_int32, [C.c_void_p, _f32p, _f32p]),
     "mmdx_model_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mmdx_deform": (C.c_int32, [C.c_void_p, _f32p, _f32p, _f32p, _f32p]),

@@ -387,6 +387,18 @@ mmdx_status mmdx_model_destroy(mmdx_model_t model) {
     return MMDX_OK;
 }
 
+mmdx_status mmdx_model_get_vertex_order(mmdx_model_t m, uint32_t *engine_to_original, uint32_t *original_to_engine) {
+    if (!m) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL");
+    const Plan &p = m->plan;
+    for (const TileHdr &t : p.tiles)
+        for (uint32_t s = 0; s < t.nv; ++s) {
+            const uint32_t e = t.v0 + s, o = t.v0 + p.perm[e];
+            if (engine_to_original) engine_to_original[e] = o;
+            if (original_to_engine) original_to_engine[o] = e;
+        }
+    return MMDX_OK;
+}
+
 mmdx_status mmdx_model_get_info(mmdx_model_t m, mmdx_model_info *info) {
     if (!m || !info) return fail(MMDX_ERR_INVALID_ARGUMENT, "model / info is NULL");
     if (info->struct_size != sizeof(mmdx_model_info))
@@ -503,6 +515,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     dp.finite_offsets = p.finite_offsets ? 1u : 0u;
     const LaunchOverrides &ov = launch_overrides();
     dp.interleave = uint32_t(ov.interleave);
+    dp.tile_order = (p.flags & MMDX_CREATE_TILE_ORDER) ? 1u : 0u;
 
     // ---- palettes -------------------------------------------------------------------------------
     const size_t pal_bytes = size_t(ni) * p.nb * 64;
@@ -615,7 +628,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // A single frame (one instance) is latency-bound: one slot per lane and twice the waves per tile finish sooner
     // (config 2: 8.4 -> 6.9 us, config 5: 16.9 -> 14.9 us).
     const bool one_frame = ni == 1 && (morph == kMorphNone || morph == kMorphFused1);
-    int threads = (ov.threads ? ov.threads : (morph == kMorphFused4 || one_frame ? 512 : 256)) == 512 ? 512 : 256;
+    // (tile-order outputs: no LDS image, 80 VGPRs with one slot per lane -- 512 threads measured 215.5 vs 219.1 us on the crowd)
+    int threads = (ov.threads ? ov.threads : (morph == kMorphFused4 || one_frame || dp.tile_order ? 512 : 256)) == 512 ? 512 : 256;
     if (morph == kMorphFused4 && threads == 512) {   // tiles with hundreds of bones: 8 palettes do not fit, 4 may
         uint32_t so, wo;
         if (deform_lds_bytes(512, layout, morph, 8, p.max_tile_bones, p.ns, &so, &wo) > 160 * 1024) threads = 256;
@@ -626,10 +640,10 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     if (morph != kMorphFused1 || ni > 1) {
         const uint32_t target = uint32_t(ov.lds_target ? ov.lds_target : (morph == kMorphFused4 ? 64 : 42) * 1024);
         uint32_t so, wo;
-        const size_t fixed = deform_lds_bytes(threads, layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo);
+        const size_t fixed = deform_lds_bytes(threads, layout, morph, 0, p.max_tile_bones, p.ns, &so, &wo, dp.tile_order != 0);
         const size_t per = size_t(p.max_tile_bones) * 48;
         uint32_t g = target > fixed ? uint32_t((target - fixed) / per) : 0u;
-        g = std::min(g, morph == kMorphFused4 ? 16u : 32u);
+        g = std::min(g, (morph == kMorphFused4 || dp.tile_order) ? 16u : 32u);   // tile order: 16 219 us, 32 229 us, 8 244 us
         if (g >= 8) g &= ~3u;   // measured: 16 beats 17 (even split of 1024 instances, aligned strides)
         g = std::max(g / gmin * gmin, gmin);
         const uint32_t ni_up = (ni + gmin - 1) / gmin * gmin;
@@ -645,7 +659,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (forced > 0) group = std::max(uint32_t(forced) / gmin * gmin, gmin);
     }
     dp.group = group;
-    const size_t lds = deform_lds_bytes(threads, layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off);
+    const size_t lds = deform_lds_bytes(threads, layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off, dp.tile_order != 0);
     if (lds > 160 * 1024)
         return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(lds) + " bytes of LDS (> 160 KiB): "
                                           "too many distinct bones in one vertex tile / too many morph slots");

@@ -556,6 +556,30 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
         // pos_scale is a separate multiply after the transform (main.cpp:848-850); x*1.0f == x
         oxy = oxy * p.pos_scale;
         oz = oz * p.pos_scale;
+        if (p.tile_order) {
+            // MMDX_CREATE_TILE_ORDER: the vertex keeps its sorted slot in the output -- consecutive lanes write consecutive
+            // vertices (12 / 32 / 6 bytes apart) straight from registers: no image, no barrier, no wave waits for another
+            const size_t v = vbase + uint32_t(tid) + uint32_t(k) * THREADS;
+            if constexpr (LAYOUT == MMDX_OUT_SOA) {
+                float *A = reinterpret_cast<float *>(p.out_a) + v * 3, *B = reinterpret_cast<float *>(p.out_b) + v * 3;
+                A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
+                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
+            } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
+                float *A = reinterpret_cast<float *>(p.out_a) + v * 8;
+                if (al) {
+                    reinterpret_cast<float4 *>(A)[0] = make_float4(oxy.x, oxy.y, oz, rxy.x);
+                    reinterpret_cast<float4 *>(A)[1] = make_float4(rxy.y, rz, q.uv.x, q.uv.y);
+                } else {
+                    A[0] = oxy.x; A[1] = oxy.y; A[2] = oz; A[3] = rxy.x; A[4] = rxy.y; A[5] = rz; A[6] = q.uv.x; A[7] = q.uv.y;
+                }
+            } else {
+                unsigned short *A = reinterpret_cast<unsigned short *>(p.out_a) + v * 3;
+                float *B = reinterpret_cast<float *>(p.out_b) + v * 3;
+                A[0] = f2h(oxy.x); A[1] = f2h(oxy.y); A[2] = f2h(oz);
+                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
+            }
+            continue;
+        }
         if constexpr (LAYOUT == MMDX_OUT_SOA) {
             float *A = reinterpret_cast<float *>(img) + sh4 + q.perm * 3;
             float *B = reinterpret_cast<float *>(img + kSoaImgBytes) + sh4 + q.perm * 3;
@@ -572,6 +596,7 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
             B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
         }
     }
+    if (p.tile_order) return;
     __syncthreads();
     const bool fast = al && nvt == kTileVerts && sh4 == 0 && sh8 == 0;
     if constexpr (LAYOUT == MMDX_OUT_SOA) {
@@ -827,7 +852,8 @@ __global__ __launch_bounds__(THREADS) void frame_kernel(const DeformParams p) {
     xform_nrm(m, q.nxy, q.nz, rxy, rz);
     oxy = oxy * p.pos_scale;                                   // a separate multiply after the transform (main.cpp:848-850)
     oz = oz * p.pos_scale;
-    const size_t v = size_t(th.v0) + q.perm;                   // original vertex index
+    // original vertex index -- or, for MMDX_CREATE_TILE_ORDER models, the vertex's sorted slot
+    const size_t v = size_t(th.v0) + (p.tile_order ? part * THREADS + uint32_t(tid) : q.perm);
     if constexpr (LAYOUT == MMDX_OUT_SOA) {
         float *A = reinterpret_cast<float *>(p.out_a) + v * 3, *B = reinterpret_cast<float *>(p.out_b) + v * 3;
         A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
@@ -1019,10 +1045,10 @@ KernelFn pick_frame(int threads, int layout, int morph, bool f16) {
 
 #ifndef MMDX_FAST_MATH
 size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
-                        uint32_t *stage_off, uint32_t *w_off) {
+                        uint32_t *stage_off, uint32_t *w_off, bool tile_order) {
     size_t off = size_t(group) * max_tile_bones * 48;
     *stage_off = uint32_t(off);
-    off += 2 * size_t(stage_bytes(layout));
+    if (!tile_order) off += 2 * size_t(stage_bytes(layout));     // tile-order outputs need no LDS image
     *w_off = uint32_t(off);
     if (morph == kMorphFused1) off += (size_t(ns + 1) * 4 + 15) / 16 * 16;
     else if (morph == kMorphFused4) off += (threads == 512 ? 2 : 1) * size_t(ns + 1) * 16;   // one or two instance quads

@@ -60,6 +60,8 @@ struct DeformParams {
     uint32_t out_aligned;        // out_a and out_b are 16-byte aligned
     uint32_t finite_offsets;     // every vertex-morph offset is finite (branch-free morph skip is exact)
     uint32_t interleave;         // crowd modes: instance = g*ngroups + grp instead of grp*group + g
+    uint32_t tile_order;         // MMDX_CREATE_TILE_ORDER: outputs in the engine's vertex order (tile-local class sort), stored straight
+                                 // from registers -- no LDS image, no per-instance barrier
 };
 
 struct FlattenParams {
@@ -73,7 +75,7 @@ struct FlattenParams {
 
 // Bytes of dynamic LDS the deform kernel needs for (layout, morph mode, group).
 size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
-                        uint32_t *stage_off, uint32_t *w_off);
+                        uint32_t *stage_off, uint32_t *w_off, bool tile_order = false);
 
 hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream);

@@ -142,9 +142,10 @@ class DeformModel:
     """mmdx_model_t: the model compiled to the kernels' HBM layout, resident on one GPU."""
 
     def __init__(self, flat: FlatModel, normalize: bool = True, f16_positions: bool = False,
-                 host_only: bool = False, fast_math: bool = False):
+                 host_only: bool = False, fast_math: bool = False, tile_order: bool = False):
         """fast_math: MMDX_CREATE_FAST_MATH -- contracted multiply-adds, results within the stated tolerance of the
-        reference's instead of bit-identical (include/mmdx.h)."""
+        reference's instead of bit-identical (include/mmdx.h).  tile_order: MMDX_CREATE_TILE_ORDER -- outputs in the
+        engine's vertex order (vertex_order() gives the permutation), same values."""
         self.flat = flat
         self.f16 = bool(f16_positions)
         self._keep = dict(
@@ -161,7 +162,8 @@ class DeformModel:
         d.flags = ((api.CREATE_NORMALIZE if normalize else 0) |
                    (api.CREATE_F16_POSITIONS if f16_positions else 0) |
                    (api.CREATE_HOST_ONLY if host_only else 0) |
-                   (api.CREATE_FAST_MATH if fast_math else 0))
+                   (api.CREATE_FAST_MATH if fast_math else 0) |
+                   (api.CREATE_TILE_ORDER if tile_order else 0))
         d.n_vertices, d.n_bones, d.n_morphs = flat.nv, flat.nb, flat.nm
         d.positions = _ptr(k["positions"], _f32p)
         d.normals = _ptr(k["normals"], _f32p)
@@ -214,6 +216,14 @@ class DeformModel:
         w = np.empty((self.nv, 4), np.float32)
         api.check(api.lib().mmdx_model_get_skin(self.h, _ptr(t, _i32p), _ptr(ids, _i32p), _ptr(w, _f32p)))
         return t, ids, w
+
+    def vertex_order(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(engine_to_original, original_to_engine): position e of a tile-order model's outputs holds file vertex
+        engine_to_original[e]."""
+        e2o, o2e = np.empty(self.nv, np.uint32), np.empty(self.nv, np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        api.check(api.lib().mmdx_model_get_vertex_order(self.h, _ptr(e2o, u32p), _ptr(o2e, u32p)))
+        return e2o, o2e
 
     def slot_weights(self, rates) -> np.ndarray:
         rates = _c(rates, np.float32)

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
 
-KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_INTERLEAVE", "MMDX_SHARED_FUSED")
+KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_INTERLEAVE", "MMDX_SHARED_FUSED", "MMDX_EXPERIMENT_DIRECT")
 
 
 def main():
@@ -33,7 +33,7 @@ def main():
     ni = 1024
     pals = synth.make_palettes(model, (np.arange(ni) * 3) % 1801)
     rates = synth.morph_weights(model.nm, 30)[0]
-    dm = DeformModel(model)
+    dm = DeformModel(model, tile_order=os.environ.get("AB_TILE_ORDER") == "1", fast_math=os.environ.get("AB_FAST_MATH") == "1")   # opt-in modes
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
     d_a, d_b, placement = dm.alloc_outputs(layout, ni, int(os.environ.get("AB_TRIES", "24")))   # AB_TRIES=1: whatever hipMalloc hands out first
     print("output placement:", placement, flush=True)

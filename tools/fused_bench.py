@@ -20,7 +20,8 @@ HBM = 8000.0
 
 
 def run(name, model, ni, frames, layout, iters, f16=False):
-    dm = DeformModel(model, f16_positions=f16)
+    dm = DeformModel(model, f16_positions=f16, tile_order=os.environ.get("FB_TILE_ORDER") == "1",
+                     fast_math=os.environ.get("FB_FAST_MATH") == "1")                     # opt-in modes
     pals = synth.make_palettes(model, frames)
     rates = synth.morph_weights(model.nm, frames)
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
