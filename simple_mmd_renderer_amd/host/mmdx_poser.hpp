@@ -78,13 +78,15 @@ public:
         std::vector<Vector3f> normals;
     } pose_image;
 
-    // `normalize` = run Model::Normalize's retagging, as both of the reference's readers do at load.
-    explicit Poser(const ModelData &m, bool normalize = true)
+    // `normalize` = run Model::Normalize's retagging, as both of the reference's readers do at load.  `extra_flags`: the engine's
+    // opt-ins -- MMDX_CREATE_FAST_MATH (results within the stated tolerance instead of bit-identical), MMDX_CREATE_TILE_ORDER
+    // (pose_image in the engine's vertex order: remap the index buffer once through VertexOrder()).
+    explicit Poser(const ModelData &m, bool normalize = true, uint32_t extra_flags = 0)
         : nv_(m.n_vertices), nb_(m.n_bones), nm_(m.n_morphs) {
         mmdx_model_desc d;
         std::memset(&d, 0, sizeof(d));
         d.struct_size = sizeof(d);
-        d.flags = normalize ? MMDX_CREATE_NORMALIZE : 0;
+        d.flags = (normalize ? MMDX_CREATE_NORMALIZE : 0) | extra_flags;
         d.n_vertices = nv_; d.n_bones = nb_; d.n_morphs = nm_;
         d.positions = m.positions.data(); d.normals = m.normals.data();
         d.uvs = m.uvs.empty() ? nullptr : m.uvs.data();
@@ -166,6 +168,15 @@ public:
         ov.n_bones = uint32_t(physics_bones_.size());
         ov.bone = physics_bones_.data(); ov.strict = physics_strict_.data(); ov.skinning = physics_skinning_.data();
         check(mmdx_skeleton_solve_post(skeleton_, model_, 1, ov.n_bones ? &ov : nullptr, 0, palette_.data()));
+    }
+
+    // original_to_engine[file vertex] = its position in pose_image of an MMDX_CREATE_TILE_ORDER poser (what the viewer's index
+    // buffer is remapped through, main.cpp:781-787); the identity-free inverse comes back in engine_to_original if asked for.
+    std::vector<uint32_t> VertexOrder(std::vector<uint32_t> *engine_to_original = nullptr) const {
+        std::vector<uint32_t> o2e(nv_);
+        if (engine_to_original) engine_to_original->resize(nv_);
+        check(mmdx_model_get_vertex_order(model_, engine_to_original ? engine_to_original->data() : nullptr, o2e.data()));
+        return o2e;
     }
 
     const std::vector<std::string> &bone_names() const { return bone_names_; }
