@@ -606,7 +606,7 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
         out["tile_order_opt_in"] = {
             "note": "MMDX_CREATE_TILE_ORDER: same values in the engine's vertex order (index buffer remapped once by the caller); measured "
                     "interleaved with the default model on the same output arrays; into plainly allocated arrays in the slow store mode "
-                    "it can be SLOWER than the default (DESIGN.md 6.1)",
+                    "the shared-morph crowd can be SLOWER than the default (DESIGN.md 4)",
             "placement": _pl}
         for name, (t_step, t_k, t_i) in res.items():
             out["tile_order_opt_in"][name] = {"config3_ms_per_step": t_step, "config3_deform_kernel_ms": t_k,

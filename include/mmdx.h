@@ -98,7 +98,8 @@ enum {
                                         morph-row length (mmdx_model_get_vertex_order returns the permutation).  Values
                                         are bit-identical to the default's, only their position in the array changes.
                                         The kernels then store straight from registers -- no on-chip transpose, no
-                                        per-instance barrier: 8-13 % more throughput for crowds and batches.  A renderer
+                                        per-instance barrier: 3 % for the shared-morph crowd, 9 % for batches with per-instance morph weights
+                                        (use with mmdx_crowd_output_alloc).  A renderer
                                         adopts it by remapping its index buffer once at load (main.cpp:781-787:
                                         index[i] = original_to_engine[index[i]]); INTEGRATION.md 1d''.                  */
 };

@@ -536,7 +536,7 @@ __device__ __forceinline__ M12 skin_matrix(const Slot &q, const float4 *P) {
 // One instance: skin the thread's slots with the palette at P (LDS), scatter the results to the LDS image `img`
 // (undoing the class sort), ONE workgroup barrier, then write the image out with coalesced 16-byte stores.
 // `inst` = the instance's index in the output arrays, cxy / cz = the (morphed) positions of the thread's slots.
-template <int THREADS, int LAYOUT, int VPT>
+template <int THREADS, int LAYOUT, int VPT, bool TILE>
 __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot (&sl)[VPT], const float4 *P,
                                               unsigned char *img, uint32_t inst, uint32_t v0, uint32_t nvt,
                                               const v2f (&cxy)[VPT], const float (&cz)[VPT], int tid) {
@@ -556,8 +556,8 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
         // pos_scale is a separate multiply after the transform (main.cpp:848-850); x*1.0f == x
         oxy = oxy * p.pos_scale;
         oz = oz * p.pos_scale;
-        if (p.tile_order) {
-            // MMDX_CREATE_TILE_ORDER: the vertex keeps its sorted slot in the output -- consecutive lanes write consecutive
+        if constexpr (TILE) {
+            // MMDX_CREATE_TILE_ORDER (a compile-time variant: the default kernels' code is untouched by it): the vertex keeps its sorted slot in the output -- consecutive lanes write consecutive
             // vertices (12 / 32 / 6 bytes apart) straight from registers: no image, no barrier, no wave waits for another
             const size_t v = vbase + uint32_t(tid) + uint32_t(k) * THREADS;
             if constexpr (LAYOUT == MMDX_OUT_SOA) {
@@ -596,7 +596,7 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
             B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
         }
     }
-    if (p.tile_order) return;
+    if constexpr (TILE) return;
     __syncthreads();
     const bool fast = al && nvt == kTileVerts && sh4 == 0 && sh8 == 0;
     if constexpr (LAYOUT == MMDX_OUT_SOA) {
@@ -632,7 +632,7 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
 
 // ---- the deformation kernel ----------------------------------------------------------------------
 // THREADS = 512: one sorted slot per lane, 8 waves per workgroup; THREADS = 256: two slots per lane.
-template <int THREADS, int LAYOUT, int MORPH, bool F16>
+template <int THREADS, int LAYOUT, int MORPH, bool F16, bool TILE>
 __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     constexpr int VPT = int(kTileVerts) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     uint32_t buf = 0;
     // the image is double buffered: the next instance writes the other one, so one barrier per instance is enough
     auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT]) {
-        skin_instance<THREADS, LAYOUT, VPT>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
+        skin_instance<THREADS, LAYOUT, VPT, TILE>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
                                             inst0 + g * istep, v0, nvt, cxy, cz, tid);
         buf ^= 1u;
     };
@@ -997,29 +997,30 @@ __global__ __launch_bounds__(kThreads) void pattern_fill_kernel(float4 *a, float
 
 using KernelFn = void (*)(const DeformParams);
 
-template <int THREADS, int LAYOUT, bool F16>
+template <int THREADS, int LAYOUT, bool F16, bool TILE>
 KernelFn pick_morph(int morph) {
     switch (morph) {
-    case kMorphNone: return deform_kernel<THREADS, LAYOUT, kMorphNone, F16>;
-    case kMorphShared: return deform_kernel<THREADS, LAYOUT, kMorphShared, F16>;
-    case kMorphFused1: return deform_kernel<THREADS, LAYOUT, kMorphFused1, F16>;
-    default: return deform_kernel<THREADS, LAYOUT, kMorphFused4, F16>;
+    case kMorphNone: return deform_kernel<THREADS, LAYOUT, kMorphNone, F16, TILE>;
+    case kMorphShared: return deform_kernel<THREADS, LAYOUT, kMorphShared, F16, TILE>;
+    case kMorphFused1: return deform_kernel<THREADS, LAYOUT, kMorphFused1, F16, TILE>;
+    default: return deform_kernel<THREADS, LAYOUT, kMorphFused4, F16, TILE>;
     }
 }
 
-template <int THREADS>
+template <int THREADS, bool TILE>
 KernelFn pick_t(int layout, int morph, bool f16) {
-    if (f16) return layout == MMDX_OUT_SOA_POS16 ? pick_morph<THREADS, MMDX_OUT_SOA_POS16, true>(morph) : nullptr;
-    if (layout == MMDX_OUT_SOA) return pick_morph<THREADS, MMDX_OUT_SOA, false>(morph);
-    if (layout == MMDX_OUT_VERTEX32) return pick_morph<THREADS, MMDX_OUT_VERTEX32, false>(morph);
+    if (f16) return layout == MMDX_OUT_SOA_POS16 ? pick_morph<THREADS, MMDX_OUT_SOA_POS16, true, TILE>(morph) : nullptr;
+    if (layout == MMDX_OUT_SOA) return pick_morph<THREADS, MMDX_OUT_SOA, false, TILE>(morph);
+    if (layout == MMDX_OUT_VERTEX32) return pick_morph<THREADS, MMDX_OUT_VERTEX32, false, TILE>(morph);
     return nullptr;
 }
 
-KernelFn pick(int threads, int layout, int morph, bool f16) {
+// tile = outputs in the engine's vertex order (MMDX_CREATE_TILE_ORDER): the direct-store variants
+KernelFn pick(int threads, int layout, int morph, bool f16, bool tile) {
 #if MMDX_TILE >= 512
-    if (threads != 256) return pick_t<512>(layout, morph, f16);
+    if (threads != 256) return tile ? pick_t<512, true>(layout, morph, f16) : pick_t<512, false>(layout, morph, f16);
 #endif
-    return pick_t<256>(layout, morph, f16);
+    return tile ? pick_t<256, true>(layout, morph, f16) : pick_t<256, false>(layout, morph, f16);
 }
 
 }  // namespace
@@ -1061,8 +1062,8 @@ hipError_t MMDX_K(prepare_kernels)() {
     for (int threads = 256; threads <= 512; threads += 256)
       for (int f16 = 0; f16 < 2; ++f16)
         for (int layout = 0; layout < 3; ++layout)
-            for (int morph = 0; morph < 4; ++morph) {
-                KernelFn fn = pick(threads, layout, morph, f16 != 0);
+            for (int morph = 0; morph < 8; ++morph) {
+                KernelFn fn = pick(threads, layout, morph & 3, f16 != 0, morph >= 4);
                 if (!fn) continue;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1084,7 +1085,7 @@ hipError_t MMDX_K(prepare_kernels)() {
 
 hipError_t MMDX_K(launch_deform)(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream) {
-    KernelFn fn = pick(threads, layout, morph, f16);
+    KernelFn fn = pick(threads, layout, morph, f16, p.tile_order != 0);
     if (!fn) return hipErrorInvalidValue;
     DeformParams q = p;
     q.ntiles = ntiles;
