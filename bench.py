@@ -202,7 +202,10 @@ def main():
     # ---- the dominant kernel, live: K back-to-back launches of the deform kernel ALONE between two HIP events on
     # its stream (MMDX_MORPH_UNCHANGED: the shared morph state did not change, the morph pass is skipped) -- the
     # kernel's duration in an uninstrumented stream, which is what a rocprofv3 kernel trace of this run shows too.
-    kernel_ms = timed_batch(kernel_only_step, args.steps)
+    # Three batches of K, the median is reported (one batch now and then catches a clock or placement hiccup: 0.2275 vs 0.2185-0.2198 ms
+    # on otherwise identical runs); all three are kept in roofline.kernel_only_batches_ms.
+    kernel_batches = [timed_batch(kernel_only_step, args.steps) for _ in range(3)]
+    kernel_ms = sorted(kernel_batches)[1]
     # ---- the old figure, kept as a named extra: events around every kernel of K more steps ---------------------
     dm.profile_enable(True)
     for _ in range(args.steps):
@@ -236,8 +239,9 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": deform_bytes, "avg_kernel_ms": kernel_ms,
-                     "avg_kernel_ms_how": f"{args.steps} back-to-back launches of the kernel alone between two HIP events "
-                                          "on its stream (rank 0)",
+                     "avg_kernel_ms_how": f"median of 3 batches of {args.steps} back-to-back launches of the kernel alone, each batch "
+                                          "between two HIP events on its stream (rank 0)",
+                     "kernel_only_batches_ms": [round(x, 5) for x in kernel_batches],
                      # the whole step (morph pass + deform kernel) against the same peak, from the driver-checkable
                      # ms_per_step: kernel and step figures must tell one story
                      "step_algorithmic_bytes": step_bytes,
@@ -247,7 +251,8 @@ def main():
                      "event_bracketed_kernel_ms": skin_avg, "event_bracketed_morph_pass_ms": morph_avg,
                      "event_bracketed_frac": deform_bytes / (skin_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      # deform-kernel launches after the timed region, oldest first (trace post-processing)
-                     "trace_segments": [["timed", args.steps], ["kernel_only", args.steps], ["event_bracketed", args.steps]],
+                     "trace_segments": [["timed", args.steps], ["kernel_only", args.steps], ["kernel_only", args.steps],
+                                        ["kernel_only", args.steps], ["event_bracketed", args.steps]],
                      "output_placement": placement,
                      "kernel_source_sha": kernel_source_sha(),
                      "settle_batches_step_ms": [round(x, 4) for x in settle_batches]},
