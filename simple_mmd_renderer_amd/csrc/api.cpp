@@ -1033,7 +1033,7 @@ mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_
     std::vector<Cand> parked;
     Cand best;
     float fill_gbs = 0.f;
-    uint32_t tries = 0;
+    uint32_t tries = 0, slow_in_a_row = 0;
     mmdx_status st = MMDX_OK;
     auto release = [](Cand &c) { if (c.a) (void)hipFree(c.a); if (c.b) (void)hipFree(c.b); c.a = c.b = nullptr; };
     for (; tries < std::max(max_tries, 1u); ) {
@@ -1069,8 +1069,12 @@ mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_
         if (launch_overrides().placement_log)
             std::fprintf(stderr, "mmdx placement try %u: a=%p b=%p store %.0f GB/s (fill %.0f)\n", tries, c.a, c.b, c.gbs, fill_gbs);
         // measured (tools/shop_probe.py): about one placement in seven is fast either way; freeing a rejected
-        // candidate at once needs a few tries less on average than keeping it parked, and no extra memory
-        const bool park = launch_overrides().placement_park != 0;
+        // candidate at once needs a few tries less on average than keeping it parked, and no extra memory.  But a process can
+        // get STUCK that way -- freed blocks come straight back, 128 tries in a row in the same slow backing (seen once in the
+        // round-2 profile runs: 0.279 instead of 0.227 ms per step) -- so after 8 slow tries in a row the rejected candidates
+        // are kept until the end (up to 48 pairs, ~60 GB of the 288): every further try then draws fresh physical memory.
+        if (c.gbs < 0.92f * fill_gbs) ++slow_in_a_row; else slow_in_a_row = 0;
+        const bool park = launch_overrides().placement_park != 0 || (slow_in_a_row >= 8 && parked.size() < 48);
         if (c.gbs > best.gbs) {
             if (best.a) { if (park) parked.push_back(best); else release(best); }
             best = c;

@@ -22,6 +22,8 @@
 //   mat x vec, <= 3 flop/B).
 #include "kernels.hpp"
 
+#include <type_traits>
+
 // MMDX_FAST_MATH (kernels_fast.hip includes this file with it defined): the SAME kernels with multiply-add contraction allowed
 // (v_fma_f32 / v_pk_fma_f32) for models created with MMDX_CREATE_FAST_MATH -- results within a stated tolerance of the
 // reference's instead of bit-identical (include/mmdx.h).  Only the deform / frame / shared-morph kernels exist in that build,
@@ -536,7 +538,7 @@ __device__ __forceinline__ M12 skin_matrix(const Slot &q, const float4 *P) {
 // One instance: skin the thread's slots with the palette at P (LDS), scatter the results to the LDS image `img`
 // (undoing the class sort), ONE workgroup barrier, then write the image out with coalesced 16-byte stores.
 // `inst` = the instance's index in the output arrays, cxy / cz = the (morphed) positions of the thread's slots.
-template <int THREADS, int LAYOUT, int VPT, bool TILE>
+template <int THREADS, int LAYOUT, int VPT, bool TILE, bool ALL_FAST>
 __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot (&sl)[VPT], const float4 *P,
                                               unsigned char *img, uint32_t inst, uint32_t v0, uint32_t nvt,
                                               const v2f (&cxy)[VPT], const float (&cz)[VPT], int tid) {
@@ -598,7 +600,9 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
     }
     if constexpr (TILE) return;
     __syncthreads();
-    const bool fast = al && nvt == kTileVerts && sh4 == 0 && sh8 == 0;
+    // ALL_FAST: the kernel found, once per workgroup, that every instance of this full tile starts on a 16-byte boundary; the
+    // generic copy-out is then not even compiled into the instance loop (1-2 % of the crowd step: measured)
+    const bool fast = ALL_FAST || (al && nvt == kTileVerts && sh4 == 0 && sh8 == 0);
     if constexpr (LAYOUT == MMDX_OUT_SOA) {
         float *oa = reinterpret_cast<float *>(p.out_a), *ob = reinterpret_cast<float *>(p.out_b);
         if (fast)
@@ -688,10 +692,16 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     __syncthreads();
 
     uint32_t buf = 0;
+    // Every output piece of this workgroup starts on a 16-byte boundary and the tile is full (all but the last tile of a model
+    // whose vertex count is a multiple of 4 -- 8 for the f16 layout): decided once, the instance loop below is instantiated twice.
+    constexpr uint32_t kAlignVerts = LAYOUT == MMDX_OUT_SOA_POS16 ? 8u : (LAYOUT == MMDX_OUT_SOA ? 4u : 1u);
+    const bool all_fast = !TILE && p.out_aligned != 0 && nvt == kTileVerts && p.nv % kAlignVerts == 0 && v0 % kAlignVerts == 0;
+    auto instances = [&](auto all_fast_tag) {
+    constexpr bool kAllFast = decltype(all_fast_tag)::value;
     // the image is double buffered: the next instance writes the other one, so one barrier per instance is enough
     auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT]) {
-        skin_instance<THREADS, LAYOUT, VPT, TILE>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
-                                            inst0 + g * istep, v0, nvt, cxy, cz, tid);
+        skin_instance<THREADS, LAYOUT, VPT, TILE, kAllFast>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
+                                                           inst0 + g * istep, v0, nvt, cxy, cz, tid);
         buf ^= 1u;
     };
 
@@ -804,6 +814,9 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             }
         }
     }
+    };   // instances
+    if (all_fast) instances(std::true_type{});
+    else instances(std::false_type{});
 }
 
 // ---- ONE frame of ONE model (ni == 1): the reference's per-frame call (main.cpp:1821) -------------------------------------
