@@ -815,8 +815,14 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         }
     }
     };   // instances
-    if (all_fast) instances(std::true_type{});
-    else instances(std::false_type{});
+    // (the one-set-of-rates kernel keeps ONE instantiation: two cost it 30 VGPRs -- 98 -> 130 -- and with them its second
+    // workgroup per CU: config 5, one frame, 14.9 -> 19.7 us)
+    if constexpr (MORPH == kMorphFused1) {
+        instances(std::false_type{});
+    } else {
+        if (all_fast) instances(std::true_type{});
+        else instances(std::false_type{});
+    }
 }
 
 // ---- ONE frame of ONE model (ni == 1): the reference's per-frame call (main.cpp:1821) -------------------------------------
