@@ -103,3 +103,38 @@ def test_tile_order_config3_crowd_full_size_sample(oracle, hip_lib):
             gu.assert_bits_equal(d_b.download((m.nv, 3), np.float32, offset=i * m.nv * 12), en[e2o], f"instance {i} nrm")
         for b in (d_pal, d_w, d_a, d_b):
             b.free()
+
+
+@gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MMDX_SOAK_SEEDS", "12"))))
+def test_tile_order_and_fast_math_randomized_models(oracle, hip_lib, seed):
+    """Random sizes / class mixes / bone windows / morph tables (duplicates, groups of groups, ignored types) -- the generator of
+    tests/test_gpu_parity.py -- through both opt-in modes: tile order bit-identical to the oracle un-permuted (per-instance morphs,
+    shared crowd, one frame), fast math within its stated tolerance."""
+    from tests.test_gpu_parity import _random_model
+    from tests.test_fast_math import close_nrm, close_pos
+    rng = np.random.RandomState(31000 + seed)
+    m = _random_model(rng)
+    ni = int(rng.choice([1, 2, 5, 9, 33]))
+    normalize = bool(rng.randint(2))
+    rates = rng.choice([0.0, 1.0, 0.3, -0.2, 5e-8, 2.5], size=(ni, m.nm)).astype(np.float32)
+    pals = synth.make_palettes(m, rng.randint(0, 500, ni))
+    skin = oracle.normalize(m) if normalize else None
+    with DeformModel(m, normalize=normalize, tile_order=True) as tm, DeformModel(m, normalize=normalize, fast_math=True) as fm:
+        e2o, _ = tm.vertex_order()
+        pos, nrm = tm.deform_batched(rates, pals)
+        spos, snrm = tm.deform_batched(rates[0], pals, shared_weights=True)
+        fpos, fnrm = fm.deform_batched(rates, pals)
+        for i in range(ni):
+            ep, en = oracle.skin(m, pals[i], oracle.morph(m, rates[i]), skin)
+            gu.assert_bits_equal(pos[i], ep[e2o], f"seed {seed} tile order inst {i} pos")
+            gu.assert_bits_equal(nrm[i], en[e2o], f"seed {seed} tile order inst {i} nrm")
+            sp, sn = oracle.skin(m, pals[i], oracle.morph(m, rates[0]), skin)
+            gu.assert_bits_equal(spos[i], sp[e2o], f"seed {seed} tile order shared inst {i} pos")
+            gu.assert_bits_equal(snrm[i], sn[e2o], f"seed {seed} tile order shared inst {i} nrm")
+            fin = np.isfinite(ep).all(axis=1) & np.isfinite(en).all(axis=1)
+            assert close_pos(fpos[i][fin], ep[fin], 1.0 + float(np.abs(pals[i]).max())) and close_nrm(fnrm[i][fin], en[fin]), f"seed {seed} fast math inst {i}"
+        p1, n1 = tm.deform(rates[ni - 1], pals[ni - 1])
+        ep, en = oracle.skin(m, pals[ni - 1], oracle.morph(m, rates[ni - 1]), skin)
+        gu.assert_bits_equal(p1, ep[e2o], "tile order frame pos")
+        gu.assert_bits_equal(n1, en[e2o], "tile order frame nrm")
