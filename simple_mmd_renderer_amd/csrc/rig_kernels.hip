@@ -482,6 +482,18 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
     V3 err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
     if (v_dot(err, err) < 1e-7f) return;
     const uint32_t ikt = ik.loop / 2;
+    // A window chain (rig.cpp: link j hangs off link j+1, the target off link 0, no append bone, no nested solve) lets the loop
+    // keep what cannot change during the solve, with the same values the reference recomputes every time: the target's own
+    // rotation and translation (only its PARENT moves), the total rotation of the links below the one being turned, and the matrix
+    // of the link placed last, which is the next one's parent -- handed on in registers instead of through the state.
+    constexpr bool kWindow = std::is_same<S, ChainState>::value;
+    Mat4 t_pre = {};                                     // the target's local matrix before its parent product
+    if constexpr (kWindow) {
+        t_pre = q_to_matrix(st.quat(tidx, kStTotalRot));
+        t_pre.m[3][0] = st.at(tidx, kStTotalTr + 0) + trec.local_offset[0];
+        t_pre.m[3][1] = st.at(tidx, kStTotalTr + 1) + trec.local_offset[1];
+        t_pre.m[3][2] = st.at(tidx, kStTotalTr + 2) + trec.local_offset[2];
+    }
     for (uint32_t i = 0; i < ik.loop; ++i) {
         for (uint32_t j = 0; j < ik.nlinks; ++j) {
             const LinkInfo lk = ch.link(j);
@@ -536,16 +548,42 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
                 ikr = q_mul(lr, q_inverse(pre));
             }
             st.set_quat(ls, kStIkRot, ikr);
-            for (uint32_t k = 0; k <= j; ++k) {
-                const uint32_t jj = j - k, bs = ch.idx(jj);
-                const Quat total = q_mul(st.quat(bs, kStIkRot), st.quat(bs, kStPreIkRot));
-                st.set_quat(bs, kStTotalRot, total);
-                place_at(st, ch.offset(jj), total, V3{st.at(bs, kStTotalTr + 0), st.at(bs, kStTotalTr + 1), st.at(bs, kStTotalTr + 2)},
-                         bs, ch.par(jj));
+            if constexpr (kWindow) {
+                Mat4 prev = {};
+                for (uint32_t k = 0; k <= j; ++k) {
+                    const uint32_t jj = j - k, bs = ch.idx(jj);
+                    Quat total;
+                    if (k == 0) {                              // the link just turned: ik_rotation * pre-IK rotation, as the reference
+                        total = q_mul(ikr, st.quat(bs, kStPreIkRot));
+                        st.set_quat(bs, kStTotalRot, total);
+                    } else {                                   // below it nothing changed: the stored product IS the recomputed one
+                        total = st.quat(bs, kStTotalRot);
+                    }
+                    Mat4 L = q_to_matrix(total);
+                    const V3 off = ch.offset(jj);
+                    L.m[3][0] = st.at(bs, kStTotalTr + 0) + off.x;
+                    L.m[3][1] = st.at(bs, kStTotalTr + 1) + off.y;
+                    L.m[3][2] = st.at(bs, kStTotalTr + 2) + off.z;
+                    if (k == 0) { if (lp >= 0) L = mul(L, loc); }   // its parent's matrix was read for the axis a moment ago
+                    else L = mul(L, prev);                     // link jj's parent is link jj+1, placed a moment ago
+                    st.set_local(bs, L);
+                    prev = L;
+                }
+                const Mat4 T = mul(t_pre, prev);               // the target hangs off link 0, the last one placed
+                st.set_local(tidx, T);
+                tgt = {T.m[3][0], T.m[3][1], T.m[3][2]};
+            } else {
+                for (uint32_t k = 0; k <= j; ++k) {
+                    const uint32_t jj = j - k, bs = ch.idx(jj);
+                    const Quat total = q_mul(st.quat(bs, kStIkRot), st.quat(bs, kStPreIkRot));
+                    st.set_quat(bs, kStTotalRot, total);
+                    place_at(st, ch.offset(jj), total, V3{st.at(bs, kStTotalTr + 0), st.at(bs, kStTotalTr + 1), st.at(bs, kStTotalTr + 2)},
+                             bs, ch.par(jj));
+                }
+                transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
+                inner(ik.target, trec.bits);
+                tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
             }
-            transform_at(st, trec, tmx, tt, tr, tidx, tpar, uint32_t(trec.append_parent));
-            inner(ik.target, trec.bits);
-            tgt = {st.at(tidx, kStLocal + 12), st.at(tidx, kStLocal + 13), st.at(tidx, kStLocal + 14)};
         }
         err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
         if (v_dot(err, err) < 1e-7f) return;
