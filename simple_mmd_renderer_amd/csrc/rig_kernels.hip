@@ -495,6 +495,7 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
         t_pre.m[3][2] = st.at(tidx, kStTotalTr + 2) + trec.local_offset[2];
     }
     for (uint32_t i = 0; i < ik.loop; ++i) {
+        bool changed = false;                               // some link's IK rotation came out different, bit for bit, in this sweep
         for (uint32_t j = 0; j < ik.nlinks; ++j) {
             const LinkInfo lk = ch.link(j);
             if (lk.fix == kFixAll) continue;
@@ -537,7 +538,8 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
             dot = 1.0f < dot ? 1.0f : dot;
             const float ac = d_acos(dot), cap = ik.angle_limit * float(j + 1);
             const float angle = cap < ac ? cap : ac;
-            Quat ikr = q_mul(axis_to_quat(axis, angle), st.quat(ls, kStIkRot));
+            const Quat ikr_old = st.quat(ls, kStIkRot);
+            Quat ikr = q_mul(axis_to_quat(axis, angle), ikr_old);
             if (lk.limited) {
                 const Quat pre = st.quat(ls, kStPreIkRot);
                 Quat lr = q_mul(ikr, pre);
@@ -548,6 +550,9 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
                 ikr = q_mul(lr, q_inverse(pre));
             }
             st.set_quat(ls, kStIkRot, ikr);
+            if constexpr (kWindow)
+                changed = changed || __float_as_uint(ikr.i) != __float_as_uint(ikr_old.i) || __float_as_uint(ikr.j) != __float_as_uint(ikr_old.j) ||
+                          __float_as_uint(ikr.k) != __float_as_uint(ikr_old.k) || __float_as_uint(ikr.e) != __float_as_uint(ikr_old.e);
             if constexpr (kWindow) {
                 Mat4 prev = {};
                 for (uint32_t k = 0; k <= j; ++k) {
@@ -587,6 +592,16 @@ __device__ void ccd(const S &st, const SerialParams &p, const float4 *pose, uint
         }
         err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
         if (v_dot(err, err) < 1e-7f) return;
+        // A sweep that reproduced every link's IK rotation bit for bit left the whole chain as it found it (each link's matrices
+        // follow from its rotation and its parent's matrix), so every later sweep with the same `i < ikt` does the same again: the
+        // rest of that half of the iterations is skipped -- the reference would run them and change nothing.  (A NaN never compares
+        // equal, so NaN chains run to the end like the reference's.)  Window chains only: nothing outside the window is involved.
+        if constexpr (kWindow) {
+            if (!changed) {
+                if (i >= ikt) return;
+                i = ikt - 1;                                // fixed during the first half: go on with the second half's rules
+            }
+        }
     }
 }
 
@@ -689,10 +704,16 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordere
     const State st = {p.state + (live ? inst : 0), p.ni};
     extern __shared__ float chain_lds[];   // (windows x instances) lanes x window_floats of state, then the
                                            // windows' link constants
+    // Which event of a round this slot runs: the events are dealt over the WAVES first (slot 4w + k runs event 4k + w), so that
+    // a round's IK solves -- the first events of the round -- sit in different waves as far as possible: lanes of one wave that
+    // solve DIFFERENT chains take turns through every divergent piece of the CCD loop (two chains per wave instead of four on the
+    // bench rig: measured).  The LDS windows belong to the round's first p.windows events, whichever slot runs them.
+    constexpr uint32_t kSlotsPerWave = 64 / kSolveInstances, kSolveWaves = kSolveSlots / kSlotsPerWave;
+    const uint32_t ev = (slot % kSlotsPerWave) * kSolveWaves + slot / kSlotsPerWave;
     const uint32_t wf = window_floats(p.fast_slots);
-    auto *lds_lane = (__attribute__((address_space(3))) float *)chain_lds + threadIdx.x * wf;
+    auto *lds_lane = (__attribute__((address_space(3))) float *)chain_lds + (ev * kSolveInstances + threadIdx.x % kSolveInstances) * wf;
     auto *lds_consts = (__attribute__((address_space(3))) float *)chain_lds +
-                       size_t(p.windows) * kSolveInstances * wf + slot * (kMaxFastLinks * kLinkConstFloats);
+                       size_t(p.windows) * kSolveInstances * wf + ev * (kMaxFastLinks * kLinkConstFloats);
     const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(live ? inst : 0) * p.nb * 2;
     if (live && (p.passes & 1u)) {
         for (uint32_t b = slot; b < p.nb; b += kSolveSlots) {   // PrePhysicsPosing's reset, poser_impl.inl:366-377
@@ -711,8 +732,8 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordere
         const uint32_t r0 = pass ? p.n_rounds_pre : 0, r1 = pass ? p.n_rounds : p.n_rounds_pre;
         for (uint32_t r = r0; r < r1; ++r) {
             const RoundRec rr = p.rounds[r];
-            if (live && slot < rr.count) {
-                const uint32_t b = p.events[rr.first + slot];
+            if (live && ev < rr.count) {
+                const uint32_t b = p.events[rr.first + ev];
                 transform_bone(st, p, pose, inst, b);
                 if (p.bones[b].bits & kBoneHasIk) solve_ik<NESTED>(st, p, pose, inst, b, lds_lane, lds_consts);
             }
