@@ -30,6 +30,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 #include <time.h>
 
@@ -640,6 +641,25 @@ static void solve_ik_chain(const solve_ctx *c, uint32_t b) {
         }
         for (int k = 0; k < 3; ++k) err[k] = ik_pos[k] - tgt_pos[k];
         if (v3_dot(err, err) < (float)MMDX_EPS_D) return;
+#ifdef MMDX_IK_CYCLE_STATS      /* diagnostic build only (tools/ik_cycle_probe.py): when does the chain's state start to repeat? */
+        if (limit >= 200) {
+            static unsigned long long hist[6];
+            static int first[2][5];
+            unsigned long long h = 1469598103934665603ull;
+            for (uint32_t q = 0; q < n; ++q) {
+                const unsigned char *pb = (const unsigned char *)&st[c->ik_link_bone[l0 + q]].ik_rot;
+                for (size_t z = 0; z < sizeof(quat_t); ++z) { h ^= pb[z]; h *= 1099511628211ull; }
+            }
+            if (i == 0) { for (int a = 0; a < 2; ++a) for (int p2 = 0; p2 < 5; ++p2) first[a][p2] = -1; }
+            const int half = i >= ikt;
+            for (int per = 1; per <= 4; ++per)
+                if (i >= (uint32_t)per && (half ? i - per >= ikt : 1) && hist[(i - per) % 6] == h && first[half][per] < 0) first[half][per] = (int)i;
+            hist[i % 6] = h;
+            if (i + 1 == limit)
+                fprintf(stderr, "ikcycle half1 p1 %d p2 %d p3 %d p4 %d | half2 p1 %d p2 %d p3 %d p4 %d\n", first[0][1], first[0][2], first[0][3],
+                        first[0][4], first[1][1], first[1][2], first[1][3], first[1][4]);
+        }
+#endif
     }
 }
 
