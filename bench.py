@@ -664,6 +664,35 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
                       "cpu_reference_palettes_per_s": ni * model3.nb / secs})
             rmot.close(); rsk.close()
         out["config3_motion_to_palettes"] = c
+        # ONE model, ONE frame, the whole of the viewer's frame() on the device (main.cpp:1786-1825 minus physics and drawing): bone
+        # tracks -> local poses -> FK palette -> morph gather + skinning, everything resident in HBM: four launches eager, one
+        # submission as a HIP-graph replay (64 frames recorded back to back).  libmmd's whole frame for this model is
+        # config2_single_frame.cpu_reference_ms_per_frame.
+        try:
+            d_fr1 = DeviceBuffer.from_numpy(np.arange(64, dtype=np.uint32) * 3)
+            d_w1 = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, np.arange(64)))
+
+            def frame(f):
+                bm.eval_device(1, d_fr1.ptr + 4 * f, d_pose.ptr, dm3)
+                sk.solve_device(1, d_pose.ptr, d_pal.ptr, dm3)
+                dm3.deform_batched_raw(1, d_w1.ptr + f * model3.nm * 4, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags_dev)
+
+            def eager64():
+                for f in range(64):
+                    frame(f)
+            ms_f = time_calls(dm3, eager64, 10) / 64
+            fr = {"gpu_ms_per_frame_eager": ms_f, "launches_per_frame": 3}
+            if not os.environ.get("MMDX_BENCH_NO_GRAPH"):
+                dm3.sync()
+                dm3.graph_begin()
+                eager64()
+                g = dm3.graph_end()
+                fr["gpu_ms_per_frame_graph_replay"] = time_calls(dm3, g.launch, 10) / 64
+                g.close()
+            out["config2_whole_frame_on_device"] = fr
+            d_fr1.free(); d_w1.free()
+        except Exception as e:                               # pragma: no cover - reporting only
+            out["config2_whole_frame_on_device"] = {"error": repr(e)}
         # the same crowd on a rig with CCD-IK chains and append bones: the ordered solver (the reference's
         # evaluation sequence cut into rounds of independent bones / IK solves).  One of the 8 chains asks for
         # 300 iterations (clamped to the reference's 256) over 3 limited links: that chain alone is the
