@@ -649,8 +649,11 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
             producer()
             dm3.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags_dev | api.WEIGHTS_SHARED)
         ms_p, ms_w = time_calls(dm3, producer, 50), time_calls(dm3, whole, 20)
+        # the same as ONE call (mmdx_skeleton_solve_motion: a workgroup per instance keeps the poses in LDS, one launch)
+        ms_p1 = time_calls(dm3, lambda: sk.solve_motion_device(bm, ni, d_fr.ptr, d_pal.ptr, dm3), 50)
         c = {"instances": ni, "bones": model3.nb, "bone_keys": bm.n_keys, "curve_tables": bm.n_curves,
              "gpu_ms_poses_plus_palettes": ms_p, "gpu_palettes_per_s": ni * model3.nb / (ms_p * 1e-3),
+             "gpu_ms_tracks_to_palettes_one_call": ms_p1, "gpu_palettes_per_s_one_call": ni * model3.nb / (ms_p1 * 1e-3),
              "gpu_ms_motion_to_vertices": ms_w, "gpu_vertices_per_s": ni * model3.nv / (ms_w * 1e-3)}
         from oracle.pyoracle import Reference, ReferenceMotion, reference_available   # checker, CPU leg only
         if reference_available():
@@ -665,7 +668,7 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
             rmot.close(); rsk.close()
         out["config3_motion_to_palettes"] = c
         # ONE model, ONE frame, the whole of the viewer's frame() on the device (main.cpp:1786-1825 minus physics and drawing): bone
-        # tracks -> local poses -> FK palette -> morph gather + skinning, everything resident in HBM: four launches eager, one
+        # tracks -> local poses -> FK palette (one launch) -> morph gather + skinning (one launch), everything resident in HBM; one
         # submission as a HIP-graph replay (64 frames recorded back to back).  libmmd's whole frame for this model is
         # config2_single_frame.cpu_reference_ms_per_frame.
         try:
@@ -673,15 +676,14 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
             d_w1 = DeviceBuffer.from_numpy(synth.morph_weights(model3.nm, np.arange(64)))
 
             def frame(f):
-                bm.eval_device(1, d_fr1.ptr + 4 * f, d_pose.ptr, dm3)
-                sk.solve_device(1, d_pose.ptr, d_pal.ptr, dm3)
+                sk.solve_motion_device(bm, 1, d_fr1.ptr + 4 * f, d_pal.ptr, dm3)      # bone tracks -> palette, one launch
                 dm3.deform_batched_raw(1, d_w1.ptr + f * model3.nm * 4, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags_dev)
 
             def eager64():
                 for f in range(64):
                     frame(f)
             ms_f = time_calls(dm3, eager64, 10) / 64
-            fr = {"gpu_ms_per_frame_eager": ms_f, "launches_per_frame": 3}
+            fr = {"gpu_ms_per_frame_eager": ms_f, "launches_per_frame": 2}
             if not os.environ.get("MMDX_BENCH_NO_GRAPH"):
                 dm3.sync()
                 dm3.graph_begin()

@@ -520,6 +520,15 @@ MMDX_API mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t skeleton, mmdx_skele
 MMDX_API mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t skeleton, mmdx_model_t model,
                                          uint32_t n_instances, const float *poses, uint32_t flags,
                                          float *out_palettes);
+/* Bone tracks -> palettes in one call: out_palettes[i][b][16] at frames[i] -- bit for bit what mmdx_bone_motion_eval followed by
+ * mmdx_skeleton_solve computes (MotionPlayer::SeekFrame + Pre/PostPhysicsPosing for every instance, main.cpp:1793-1810).  On a
+ * skeleton that runs the parallel FK solver it is ONE launch and the [NI][NB][8] local poses never leave the chip (a workgroup per
+ * instance keeps them in LDS); skeletons with append bones / IK and those of more than 2 048 bones take the two launches, the poses
+ * in the motion's scratch buffer.  `motion` must have been bound to this skeleton's bones.  flags: MMDX_FRAMES_ON_DEVICE |
+ * MMDX_OUT_ON_DEVICE; stream and device as for mmdx_bone_motion_eval; recordable into a graph. */
+MMDX_API mmdx_status mmdx_skeleton_solve_motion(mmdx_skeleton_t skeleton, mmdx_bone_motion_t motion, mmdx_model_t model,
+                                                uint32_t n_instances, const uint32_t *frames, uint32_t flags,
+                                                float *out_palettes);
 /* The same with bone morphs applied first: morph_weights[i][n_morphs] (or one shared row with
  * MMDX_WEIGHTS_SHARED; device pointer with MMDX_WEIGHTS_ON_DEVICE) are the raw per-frame morph rates, the
  * ones mmdx_deform_batched takes.  Bone-morph rotations go through SLerp, i.e. through the device's double

@@ -123,6 +123,7 @@ SIGNATURES = {
     "mmdx_skeleton_create": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mmdx_skeleton_get_info": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mmdx_skeleton_solve": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "mmdx_skeleton_solve_motion": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mmdx_skeleton_solve_morphed": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                                 C.c_void_p]),
     "mmdx_skeleton_solve_pre": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,

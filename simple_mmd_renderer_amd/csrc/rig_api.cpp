@@ -75,6 +75,56 @@ struct mmdx_skeleton_s {
     }
 };
 
+// static tables of a motion / a skeleton -> the device they are about to run on (once per device)
+static mmdx_status motion_to_device(mmdx_bone_motion_t m, int device) {
+    if (m->device == device) return MMDX_OK;
+    const BoneMotionHost &h = m->host;
+    for (Buf *b : {&m->key_off, &m->key_frame, &m->key_tr, &m->key_rot, &m->key_curve, &m->lut, &m->frames_in, &m->out})
+        b->release();
+    HIP_TRY(m->key_off.upload(h.key_off));
+    HIP_TRY(m->key_frame.upload(h.key_frame));
+    HIP_TRY(m->key_tr.upload(h.key_tr));
+    HIP_TRY(m->key_rot.upload(h.key_rot));
+    HIP_TRY(m->key_curve.upload(h.key_curve));
+    HIP_TRY(m->lut.upload(h.lut));
+    m->device = device;
+    return MMDX_OK;
+}
+static BoneTrackParams motion_params(mmdx_bone_motion_t m, uint32_t n_instances) {
+    BoneTrackParams p;
+    p.key_off = static_cast<const uint32_t *>(m->key_off.ptr);
+    p.key_frame = static_cast<const uint32_t *>(m->key_frame.ptr);
+    p.key_tr = static_cast<const float *>(m->key_tr.ptr);
+    p.key_rot = static_cast<const float *>(m->key_rot.ptr);
+    p.key_curve = static_cast<const uint32_t *>(m->key_curve.ptr);
+    p.lut = static_cast<const float *>(m->lut.ptr);
+    p.frames = nullptr; p.out = nullptr;
+    p.nb = m->host.nb; p.ni = n_instances;
+    return p;
+}
+static mmdx_status skeleton_to_device(mmdx_skeleton_t s, int device) {
+    if (s->device == device) return MMDX_OK;
+    const SkeletonPlan &pl = s->plan;
+    s->release_all();
+    HIP_TRY(s->apps.upload(pl.apps));
+    HIP_TRY(s->app_chain.upload(pl.app_chain));
+    if (pl.serial) {
+        HIP_TRY(s->order.upload(pl.order));
+        HIP_TRY(s->bones.upload(pl.bones));
+        HIP_TRY(s->iks.upload(pl.iks));
+        HIP_TRY(s->links.upload(pl.links));
+        HIP_TRY(s->events.upload(pl.events));
+        HIP_TRY(s->rounds.upload(pl.rounds));
+    } else {
+        HIP_TRY(s->local_offset.upload(pl.local_offset));
+        HIP_TRY(s->neg_rest.upload(pl.neg_rest));
+        HIP_TRY(s->chain_off.upload(pl.chain_off));
+        HIP_TRY(s->chain.upload(pl.chain));
+    }
+    s->device = device;
+    return MMDX_OK;
+}
+
 static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances, const float *poses,
                                   const float *morph_weights, uint32_t flags, float *out_palettes, uint32_t passes,
                                   const mmdx_physics_overrides *ov);
@@ -118,26 +168,8 @@ mmdx_status mmdx_bone_motion_eval(mmdx_bone_motion_t m, mmdx_model_t model, uint
                               m->device != device))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory and the "
                                                "motion must have run on this device before");
-    if (m->device != device) {
-        for (Buf *b : {&m->key_off, &m->key_frame, &m->key_tr, &m->key_rot, &m->key_curve, &m->lut, &m->frames_in,
-                       &m->out})
-            b->release();
-        HIP_TRY(m->key_off.upload(h.key_off));
-        HIP_TRY(m->key_frame.upload(h.key_frame));
-        HIP_TRY(m->key_tr.upload(h.key_tr));
-        HIP_TRY(m->key_rot.upload(h.key_rot));
-        HIP_TRY(m->key_curve.upload(h.key_curve));
-        HIP_TRY(m->lut.upload(h.lut));
-        m->device = device;
-    }
-    BoneTrackParams p;
-    p.key_off = static_cast<const uint32_t *>(m->key_off.ptr);
-    p.key_frame = static_cast<const uint32_t *>(m->key_frame.ptr);
-    p.key_tr = static_cast<const float *>(m->key_tr.ptr);
-    p.key_rot = static_cast<const float *>(m->key_rot.ptr);
-    p.key_curve = static_cast<const uint32_t *>(m->key_curve.ptr);
-    p.lut = static_cast<const float *>(m->lut.ptr);
-    p.nb = h.nb; p.ni = n_instances;
+    if (mmdx_status r = motion_to_device(m, device)) return r;
+    BoneTrackParams p = motion_params(m, n_instances);
     if (flags & MMDX_FRAMES_ON_DEVICE) {
         p.frames = frames;
     } else {
@@ -202,6 +234,70 @@ mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t s, mmdx_skeleton_info *info) 
     return MMDX_OK;
 }
 
+mmdx_status mmdx_skeleton_solve_motion(mmdx_skeleton_t s, mmdx_bone_motion_t m, mmdx_model_t model, uint32_t n_instances,
+                                       const uint32_t *frames, uint32_t flags, float *out_palettes) {
+    if (!s || !m || !frames || !out_palettes || !n_instances)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
+    if (m->host.nb != s->plan.nb)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "the motion was bound to " + std::to_string(m->host.nb) + " bones, the skeleton has " +
+                                               std::to_string(s->plan.nb));
+    int device;
+    hipStream_t st;
+    if (mmdx_status r = resolve_stream(model, &device, &st)) return r;
+    const SkeletonPlan &pl = s->plan;
+    const size_t pose_bytes = size_t(n_instances) * pl.nb * MMDX_POSE_FLOATS * sizeof(float);
+    if (pl.serial || size_t(pl.nb) * 32 > kMotionFkMaxLds) {
+        // append bones / IK (the ordered solver) or a skeleton too large for the LDS pose table: the two launches, the poses in the
+        // motion's scratch buffer
+        if (graph_recording() && m->out.bytes < pose_bytes)
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "run the call once before recording: it sizes the motion's pose buffer");
+        if (mmdx_status r = motion_to_device(m, device)) return r;
+        HIP_TRY(m->out.ensure(pose_bytes));
+        if (mmdx_status r = mmdx_bone_motion_eval(m, model, n_instances, frames, (flags & MMDX_FRAMES_ON_DEVICE) | MMDX_OUT_ON_DEVICE,
+                                                  static_cast<float *>(m->out.ptr)))
+            return r;
+        return mmdx_skeleton_solve(s, model, n_instances, static_cast<const float *>(m->out.ptr),
+                                   MMDX_POSES_ON_DEVICE | (flags & MMDX_OUT_ON_DEVICE), out_palettes);
+    }
+    if (graph_recording() && ((flags & (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE)) != (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE) ||
+                              m->device != device || s->device != device))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory and the motion "
+                                               "and the skeleton must have run on this device before");
+    if (mmdx_status r = motion_to_device(m, device)) return r;
+    if (mmdx_status r = skeleton_to_device(s, device)) return r;
+    BoneTrackParams tp = motion_params(m, n_instances);
+    if (flags & MMDX_FRAMES_ON_DEVICE) {
+        tp.frames = frames;
+    } else {
+        HIP_TRY(m->frames_in.ensure(size_t(n_instances) * 4));
+        HIP_TRY(hipMemcpyAsync(m->frames_in.ptr, frames, size_t(n_instances) * 4, hipMemcpyHostToDevice, st));
+        tp.frames = static_cast<const uint32_t *>(m->frames_in.ptr);
+    }
+    const size_t out_bytes = size_t(n_instances) * pl.nb * 16 * sizeof(float);
+    SkeletonParams fp;
+    fp.morph = nullptr;
+    fp.poses = nullptr;
+    if (flags & MMDX_OUT_ON_DEVICE) {
+        fp.out = out_palettes;
+    } else {
+        HIP_TRY(s->out.ensure(out_bytes));
+        fp.out = static_cast<float *>(s->out.ptr);
+    }
+    fp.local_offset = static_cast<const float *>(s->local_offset.ptr);
+    fp.neg_rest = static_cast<const float *>(s->neg_rest.ptr);
+    fp.chain_off = static_cast<const uint32_t *>(s->chain_off.ptr);
+    fp.chain = static_cast<const uint32_t *>(s->chain.ptr);
+    fp.nb = pl.nb; fp.ni = n_instances;
+    HIP_TRY(launch_motion_fk(tp, fp, st));
+    if (!(flags & MMDX_OUT_ON_DEVICE)) {
+        HIP_TRY(hipMemcpyAsync(out_palettes, fp.out, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(wait_stream(st));
+    } else if (!(flags & MMDX_FRAMES_ON_DEVICE)) {
+        HIP_TRY(wait_stream(st));                    // the borrowed host frame numbers must be consumed before returning
+    }
+    return MMDX_OK;
+}
+
 mmdx_status mmdx_skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_t n_instances, const float *poses,
                                 uint32_t flags, float *out_palettes) {
     return mmdx_skeleton_solve_morphed(s, model, n_instances, poses, nullptr, flags, out_palettes);
@@ -257,25 +353,7 @@ static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_
                                                    "skeleton must have run on this device before, and physics overrides "
                                                    "(host lists) are not recordable");
     }
-    if (s->device != device) {
-        s->release_all();
-        HIP_TRY(s->apps.upload(pl.apps));
-        HIP_TRY(s->app_chain.upload(pl.app_chain));
-        if (pl.serial) {
-            HIP_TRY(s->order.upload(pl.order));
-            HIP_TRY(s->bones.upload(pl.bones));
-            HIP_TRY(s->iks.upload(pl.iks));
-            HIP_TRY(s->links.upload(pl.links));
-            HIP_TRY(s->events.upload(pl.events));
-            HIP_TRY(s->rounds.upload(pl.rounds));
-        } else {
-            HIP_TRY(s->local_offset.upload(pl.local_offset));
-            HIP_TRY(s->neg_rest.upload(pl.neg_rest));
-            HIP_TRY(s->chain_off.upload(pl.chain_off));
-            HIP_TRY(s->chain.upload(pl.chain));
-        }
-        s->device = device;
-    }
+    if (mmdx_status r = skeleton_to_device(s, device)) return r;
     struct { const float *poses; float *out; } p;
     const size_t in_bytes = size_t(n_instances) * pl.nb * MMDX_POSE_FLOATS * sizeof(float);
     const size_t out_bytes = size_t(n_instances) * pl.nb * 16 * sizeof(float);

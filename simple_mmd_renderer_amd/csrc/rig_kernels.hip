@@ -8,6 +8,7 @@
 #include "rig.hpp"
 #include "rig_kernels.hpp"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace mmdx {
@@ -26,12 +27,9 @@ __device__ __forceinline__ float curve_at(const float *lut, uint32_t id, float x
     return t[kCurveSamples - 1];
 }
 
-// Motion::GetBonePose(name, frame), L/motion/motion_impl.inl:255-319.
-__global__ __launch_bounds__(kRigThreads) void bone_track_eval_kernel(const BoneTrackParams p) {
-    const size_t idx = size_t(blockIdx.x) * kRigThreads + threadIdx.x;
-    if (idx >= size_t(p.ni) * p.nb) return;
-    const uint32_t i = uint32_t(idx / p.nb), bone = uint32_t(idx - size_t(i) * p.nb);
-    const uint32_t b = p.key_off[bone], e = p.key_off[bone + 1], frame = p.frames[i];
+// Motion::GetBonePose(name, frame), L/motion/motion_impl.inl:255-319: the local pose (translation, rotation) of one bone at one frame.
+__device__ __forceinline__ void eval_bone_pose(const BoneTrackParams &p, uint32_t bone, uint32_t frame, float4 &t_out, float4 &q_out) {
+    const uint32_t b = p.key_off[bone], e = p.key_off[bone + 1];
     const float4 *tr = reinterpret_cast<const float4 *>(p.key_tr);
     const float4 *rot = reinterpret_cast<const float4 *>(p.key_rot);
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 1.f);   // Poser::ResetPosing
@@ -84,6 +82,16 @@ __global__ __launch_bounds__(kRigThreads) void bone_track_eval_kernel(const Bone
             }
         }
     }
+    t_out = t;
+    q_out = q;
+}
+
+__global__ __launch_bounds__(kRigThreads) void bone_track_eval_kernel(const BoneTrackParams p) {
+    const size_t idx = size_t(blockIdx.x) * kRigThreads + threadIdx.x;
+    if (idx >= size_t(p.ni) * p.nb) return;
+    const uint32_t i = uint32_t(idx / p.nb), bone = uint32_t(idx - size_t(i) * p.nb);
+    float4 t, q;
+    eval_bone_pose(p, bone, p.frames[i], t, q);
     float4 *out = reinterpret_cast<float4 *>(p.out) + idx * 2;
     out[0] = t;
     out[1] = q;
@@ -131,11 +139,8 @@ __device__ __forceinline__ Mat4 mul(const Mat4 &a, const Mat4 &b) {
 // down (local(c) * local(parent), the association the reference's in-order sweep produces), then
 // skinning = global_offset * local (L/motion/poser_impl.inl:320-326).  Chains are short (rig depth),
 // poses and chain lists are L2-resident, and nothing synchronises: 1024 x 300 bones is one wave per CU.
-__global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const SkeletonParams p) {
-    const size_t idx = size_t(blockIdx.x) * kRigThreads + threadIdx.x;
-    if (idx >= size_t(p.ni) * p.nb) return;
-    const uint32_t i = uint32_t(idx / p.nb), bone = uint32_t(idx - size_t(i) * p.nb);
-    const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(i) * p.nb * 2;
+template <class PoseAt>
+__device__ __forceinline__ void fk_bone(const SkeletonParams &p, PoseAt pose_at, uint32_t i, uint32_t bone, float4 *out) {
     const float4 *off = reinterpret_cast<const float4 *>(p.local_offset);
     uint32_t c0 = p.chain_off[bone];
     const uint32_t c1 = p.chain_off[bone + 1];
@@ -157,8 +162,7 @@ __global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const Skeleton
             mt[0] = ms[0]; mt[1] = ms[size_t(p.ni)]; mt[2] = ms[2 * size_t(p.ni)];
             mq[0] = ms[3 * size_t(p.ni)]; mq[1] = ms[4 * size_t(p.ni)]; mq[2] = ms[5 * size_t(p.ni)]; mq[3] = ms[6 * size_t(p.ni)];
         }
-        const Mat4 L = local_matrix(pose[2 * size_t(b)], pose[2 * size_t(b) + 1], off[b], mt[0], mt[1], mt[2], mq[0],
-                                    mq[1], mq[2], mq[3]);
+        const Mat4 L = local_matrix(pose_at(2 * b), pose_at(2 * b + 1), off[b], mt[0], mt[1], mt[2], mq[0], mq[1], mq[2], mq[3]);
         M = have ? mul(L, M) : L;
         have = true;
     }
@@ -170,9 +174,39 @@ __global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const Skeleton
         for (int x = 0; x < 4; ++x) G.m[y][x] = x == y ? 1.f : 0.f;
     G.m[3][0] = g.x; G.m[3][1] = g.y; G.m[3][2] = g.z;
     const Mat4 S = mul(G, M);
-    float4 *out = reinterpret_cast<float4 *>(p.out) + idx * 4;
 #pragma unroll
     for (int y = 0; y < 4; ++y) out[y] = make_float4(S.m[y][0], S.m[y][1], S.m[y][2], S.m[y][3]);
+}
+
+__global__ __launch_bounds__(kRigThreads) void skeleton_fk_kernel(const SkeletonParams p) {
+    const size_t idx = size_t(blockIdx.x) * kRigThreads + threadIdx.x;
+    if (idx >= size_t(p.ni) * p.nb) return;
+    const uint32_t i = uint32_t(idx / p.nb), bone = uint32_t(idx - size_t(i) * p.nb);
+    const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(i) * p.nb * 2;
+    fk_bone(p, [&](uint32_t k) { return pose[k]; }, i, bone, reinterpret_cast<float4 *>(p.out) + idx * 4);
+}
+
+// Bone tracks -> palette in ONE launch (mmdx_skeleton_solve_motion on a parallel-FK skeleton): a workgroup is one instance; its
+// threads evaluate the bones' local poses at the instance's frame into LDS (eval_bone_pose: what bone_track_eval_kernel writes to
+// HBM), one barrier, then every thread rebuilds its bones' matrices from those poses (fk_bone: what skeleton_fk_kernel does from
+// HBM).  The same two functions, so the same bits; the [NI][NB][8] pose array never leaves the chip (it is still written out when
+// the caller asks for it: t.out != nullptr).
+__global__ __launch_bounds__(1024) void motion_fk_kernel(const BoneTrackParams t, const SkeletonParams p) {
+    extern __shared__ float4 pose_lds[];                 // [nb][2]
+    const uint32_t i = blockIdx.x, frame = t.frames[i];
+    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) {   // one bone per thread up to 1 024 bones: one latency chain, not several
+        float4 tr, q;
+        eval_bone_pose(t, b, frame, tr, q);
+        pose_lds[2 * b] = tr;
+        pose_lds[2 * b + 1] = q;
+        if (t.out) {
+            float4 *o = reinterpret_cast<float4 *>(t.out) + (size_t(i) * p.nb + b) * 2;
+            o[0] = tr; o[1] = q;
+        }
+    }
+    __syncthreads();
+    for (uint32_t bone = threadIdx.x; bone < p.nb; bone += blockDim.x)
+        fk_bone(p, [&](uint32_t k) { return pose_lds[k]; }, i, bone, reinterpret_cast<float4 *>(p.out) + (size_t(i) * p.nb + bone) * 4);
 }
 
 // ---- ordered solver: append (inherit) bones + CCD-IK -----------------------------------------------
@@ -892,6 +926,15 @@ hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(skeleton_fk_kernel, dim3(uint32_t((n + kRigThreads - 1) / kRigThreads)),
                        dim3(kRigThreads), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_motion_fk(const BoneTrackParams &t, const SkeletonParams &p, hipStream_t stream) {
+    if (p.ni == 0 || p.nb == 0) return hipSuccess;
+    const size_t lds = size_t(p.nb) * 32;
+    if (lds > kMotionFkMaxLds) return hipErrorInvalidValue;                  // callers check: the two-launch path takes over
+    const uint32_t threads = std::min<uint32_t>(1024u, (p.nb + 63u) / 64u * 64u);
+    hipLaunchKernelGGL(motion_fk_kernel, dim3(p.ni), dim3(threads), lds, stream, t, p);
     return hipGetLastError();
 }
 

@@ -323,6 +323,20 @@ class Skeleton:
                                                      self._seam_out.ctypes.data))
         return self._seam_out.copy()
 
+    # -- bone tracks -> palettes in one call (one launch on parallel-FK skeletons: the poses stay in LDS) -------------
+    def solve_motion(self, motion: "BoneMotion", frames, model=None) -> np.ndarray:
+        """Host convenience: frame numbers [NI] -> palettes f32 [NI, NB, 16] (= solve(motion.eval(frames)))."""
+        f = np.ascontiguousarray(frames, np.uint32).reshape(-1)
+        out = np.empty((f.size, self.nb, 16), np.float32)
+        api.check(api.lib().mmdx_skeleton_solve_motion(self.h, motion.h, model.h if model is not None else None, f.size,
+                                                       f.ctypes.data, 0, out.ctypes.data))
+        return out
+
+    def solve_motion_device(self, motion: "BoneMotion", n_instances: int, frames_ptr, out_ptr, model=None) -> None:
+        """Frame numbers and palettes resident in HBM; asynchronous on the model's stream."""
+        api.check(api.lib().mmdx_skeleton_solve_motion(self.h, motion.h, model.h if model is not None else None, n_instances,
+                                                       frames_ptr, FRAMES_ON_DEVICE | api.OUT_ON_DEVICE, out_ptr))
+
     def solve_device(self, n_instances: int, poses_ptr, out_ptr, model=None, weights_ptr=None, shared=False) -> None:
         """poses, palettes (and morph rates) resident in HBM; asynchronous on the model's stream."""
         flags = POSES_ON_DEVICE | api.OUT_ON_DEVICE | (api.WEIGHTS_ON_DEVICE if weights_ptr else 0) | \

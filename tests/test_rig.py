@@ -722,3 +722,49 @@ def test_gpu_nested_ik_three_deep(oracle):
     for i in range(poses.shape[0]):
         want = oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, deep)
         gu.assert_bits_equal_or_both_nan(got[i], want, f"palette of instance {i}")
+
+
+# ---- bone tracks -> palettes in one call (mmdx_skeleton_solve_motion) ------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,fwd,post,levels,seed", [(1, 0, 0.0, 1, 0), (40, 5, 0.25, 3, 2), (300, 20, 0.3, 4, 3), (2048, 100, 0.1, 5, 5),
+                                                     (2500, 10, 0.0, 2, 6)])
+def test_gpu_solve_motion_equals_eval_then_solve_and_oracle(oracle, nb, fwd, post, levels, seed):
+    """mmdx_skeleton_solve_motion on parallel-FK skeletons (one launch, the poses in LDS; 2 500 bones: more than the LDS table holds,
+    the two launches inside) is bit-identical to mmdx_bone_motion_eval + mmdx_skeleton_solve -- host and device operands -- and to
+    the oracle run step by step."""
+    rest, parent, level, flags = synth.make_skeleton(nb, seed, fwd, post, levels)
+    names = [f"bone{i}" for i in range(nb)]
+    keys = synth.make_bone_keys(names[:min(nb, 60)], 40 + seed, keys_per=5, span=300)
+    v = vmd.Vmd(vmd.write_vmd(keys, []))
+    bm = v.bind_bones(names)
+    sk = vmd.Skeleton(rest, parent, level, flags)
+    frames = np.r_[np.arange(0, 320, 37), 5, 5, 4_000_000_000].astype(np.uint32)
+    ni = frames.size
+    two = sk.solve(bm.eval(frames))
+    one = sk.solve_motion(bm, frames)
+    gu.assert_bits_equal(one, two, "host operands")
+    d_fr, d_pal = DeviceBuffer.from_numpy(frames), DeviceBuffer(ni * nb * 64)
+    d_pal.memset(0xFF)
+    sk.solve_motion_device(bm, ni, d_fr.ptr, d_pal.ptr)
+    api.check(api.lib().mmdx_device_synchronize())
+    gu.assert_bits_equal(d_pal.download((ni, nb, 16), np.float32), two, "device operands")
+    poses = oracle_poses(oracle, v, names, frames)
+    for i in (0, ni - 1):
+        gu.assert_bits_equal(one[i], oracle.bone_solve(rest, parent, poses[i], level, flags), f"oracle, instance {i}")
+    d_fr.free(); d_pal.free()
+
+
+@pytest.mark.gpu
+def test_gpu_solve_motion_on_an_ik_rig_takes_the_ordered_solver():
+    """A rig with append bones and CCD-IK: the call evaluates the tracks into the motion's scratch buffer and runs the ordered solver --
+    the same bits as the two calls; a motion bound to another bone count is rejected."""
+    nb = 48
+    rig = synth.make_ik_rig(nb, 77, n_ik=3, n_append=4)
+    names = [f"b{i}" for i in range(nb)]
+    v = vmd.Vmd(vmd.write_vmd(synth.make_bone_keys(names, 9, keys_per=4, span=100), []))
+    bm, sk = v.bind_bones(names), vmd.Skeleton(*rig)
+    assert sk.info["solver"] == 1
+    frames = np.arange(0, 110, 7, dtype=np.uint32)
+    gu.assert_bits_equal(sk.solve_motion(bm, frames), sk.solve(bm.eval(frames)), "ordered solver")
+    with pytest.raises(api.MmdxError, match="bones"):
+        sk.solve_motion(v.bind_bones(names[:-1]), frames)

@@ -27,4 +27,6 @@ rigs = {"fk": vmdmod.Skeleton(m.bone_pos, np.asarray(m.bone_parent, np.int32)),
 for name, sk in rigs.items():
     ms = bench.time_calls(dm, lambda: (bm.eval_device(ni, d_fr.ptr, d_pose.ptr, dm), sk.solve_device(ni, d_pose.ptr, d_pal.ptr, dm)),
                           10 if name == "ik" else 30)
-    print(f"{name:7s} rig: poses + palettes of {ni} x {m.nb} bones  {ms * 1e3:9.1f} us   solver {sk.info['solver']} rounds {sk.info['n_solve_rounds']}", flush=True)
+    ms1 = bench.time_calls(dm, lambda: sk.solve_motion_device(bm, ni, d_fr.ptr, d_pal.ptr, dm), 10 if name == "ik" else 30)
+    print(f"{name:7s} rig: poses + palettes of {ni} x {m.nb} bones  {ms * 1e3:9.1f} us   as one call {ms1 * 1e3:9.1f} us   "
+          f"solver {sk.info['solver']} rounds {sk.info['n_solve_rounds']}", flush=True)
