@@ -93,3 +93,46 @@ def test_graph_whole_frame_motion_to_vertices(oracle):
         for b in (d_fr, d_pose, d_pal, d_w, d_a, d_b):
             b.free()
     sk.close()
+
+
+def test_graph_frame_with_the_one_call_palette_producer(oracle):
+    """mmdx_skeleton_solve_motion (bone tracks -> palettes, one launch) + the frame kernel recorded as one graph: replays for new
+    frame numbers and rates reproduce the eager calls bit for bit; before its first eager run a recording is rejected."""
+    m = synth.make_model(3000, 40, 6, 200, seed=78)
+    names = [f"b{i}" for i in range(m.nb)]
+    v = vmd.Vmd(vmd.write_vmd(synth.make_bone_keys(names, 6, keys_per=8, span=120), []))
+    bm = v.bind_bones(names)
+    sk = vmd.Skeleton(m.bone_pos, np.asarray(m.bone_parent, np.int32))
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+    with DeformModel(m) as dm:
+        d_fr = DeviceBuffer.from_numpy(np.zeros(1, np.uint32))
+        d_pal, d_w = DeviceBuffer(m.nb * 64), DeviceBuffer.from_numpy(synth.morph_weights(m.nm, 0)[0])
+        sa, sb = dm.out_sizes(api.OUT_SOA, 1)
+        d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+
+        def frame():
+            sk.solve_motion_device(bm, 1, d_fr.ptr, d_pal.ptr, dm)
+            dm.deform_batched_raw(1, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+        dm.graph_begin()
+        with pytest.raises(api.MmdxError):               # the motion / skeleton tables are not on the device yet
+            sk.solve_motion_device(bm, 1, d_fr.ptr, d_pal.ptr, dm)
+        dm.graph_end().close()
+        frame()
+        dm.sync()
+        dm.graph_begin()
+        frame()
+        g = dm.graph_end()
+        for rep in range(3):
+            d_fr.upload(np.asarray([17 * rep + 3], np.uint32)); d_w.upload(synth.morph_weights(m.nm, 40 * rep)[0])
+            frame()
+            dm.sync()
+            want_a, want_b = d_a.download((m.nv, 3), np.float32), d_b.download((m.nv, 3), np.float32)
+            d_a.memset(0); d_b.memset(0)
+            g.launch()
+            dm.sync()
+            gu.assert_bits_equal(d_a.download((m.nv, 3), np.float32), want_a, f"rep {rep} pos")
+            gu.assert_bits_equal(d_b.download((m.nv, 3), np.float32), want_b, f"rep {rep} nrm")
+        g.close()
+        for b in (d_fr, d_pal, d_w, d_a, d_b):
+            b.free()
+    sk.close()
