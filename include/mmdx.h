@@ -33,6 +33,8 @@
  *     re-entrant; different handles (and devices) may be driven from different host threads.
  *   - Results are bit-identical to the reference's CPU path (the kernels are compiled with
  *     -ffp-contract=off and keep the reference's operation order); see DESIGN.md.
+ *   - Measurement and A/B helpers that no reference interface corresponds to (event timers, per-kernel
+ *     profiling, copy / fill / store-pattern ceilings, launch-shape overrides) live in mmdx_bench.h.
  */
 #ifndef MMDX_H_INCLUDED
 #define MMDX_H_INCLUDED
@@ -50,7 +52,9 @@ extern "C" {
 #define MMDX_API
 #endif
 
-#define MMDX_ABI_VERSION 1u
+/* 2: mmdx_skeleton_desc.create_flags (was reserved0), the physics seam and graph entry points, unknown flag bits are
+ *    rejected, bench / debug entry points moved to mmdx_bench.h (same library). */
+#define MMDX_ABI_VERSION 2u
 
 typedef int32_t mmdx_status;
 enum {
@@ -218,7 +222,13 @@ MMDX_API mmdx_status mmdx_model_set_stream(mmdx_model_t model, void *hip_stream)
  * frame of motion -> poses -> palettes -> vertices is four to six launches (~4 us of host time each); the device-side
  * gaps between dependent kernels are the same either way.  Rules: run the same sequence once un-captured first (it
  * sizes the handles' scratch buffers; a call that would have to allocate while recording fails), no host operands,
- * no mmdx_profile_enable while recording, one recording per model at a time. */
+ * no mmdx_profile_enable while recording, one recording per model at a time; mmdx_graph_end on the thread that called
+ * mmdx_graph_begin.
+ * Lifetime: a graph holds raw device addresses of the scratch buffers of every handle that took part in the recording
+ * (the model, and skeletons / motions called with it).  While the graph is alive those handles are pinned: a later call
+ * on them that would have to GROW such a buffer fails with MMDX_ERR_INVALID_ARGUMENT instead of moving it (size the
+ * buffers with an un-recorded call of the largest shape first); destroying a pinned handle is allowed and invalidates
+ * the graph -- mmdx_graph_launch then fails, it never replays into freed memory. */
 typedef struct mmdx_graph_s *mmdx_graph_t;
 MMDX_API mmdx_status mmdx_graph_begin(mmdx_model_t model);
 MMDX_API mmdx_status mmdx_graph_end(mmdx_model_t model, mmdx_graph_t *out_graph);
@@ -239,21 +249,6 @@ MMDX_API mmdx_status mmdx_deform_vertex32(mmdx_model_t model, const float *morph
 MMDX_API mmdx_status mmdx_deform_batched(mmdx_model_t model, const mmdx_deform_args *args);
 MMDX_API mmdx_status mmdx_sync(mmdx_model_t model);
 
-/* ---- timing on the handle's stream (HIP events; for bench harnesses) ------------------------- */
-MMDX_API mmdx_status mmdx_timer_start(mmdx_model_t model);
-MMDX_API mmdx_status mmdx_timer_stop(mmdx_model_t model, float *elapsed_ms); /* syncs the stream  */
-/* Per-kernel timing with no host synchronisation: while enabled, mmdx_deform_batched records HIP events on
- * the launch stream around its morph kernels and around its skinning kernel -- on every call (enabled == 1)
- * or on every N-th call (enabled == N > 1): the four event records cost the stream about 7 us per call, which a
- * throughput measurement should not pay on every step.  (Timing the skinning kernel alone is not offered: its
- * start event must follow another event record, or it is stamped with the end of the previous KERNEL and the
- * interval then includes the launch gap.)  mmdx_profile_collect waits for the recorded calls, returns how
- * many were timed and the summed milliseconds of the skinning kernel and of the morph pass, and resets
- * the recording. */
-MMDX_API mmdx_status mmdx_profile_enable(mmdx_model_t model, int32_t enabled);
-MMDX_API mmdx_status mmdx_profile_collect(mmdx_model_t model, uint32_t *n_calls, float *skin_ms_total,
-                                          float *morph_ms_total);
-
 /* ---- plain device-memory helpers (thin hipMalloc / hipMemcpy wrappers) ----------------------- */
 /* So that C, C++ and ctypes callers can keep palettes and outputs resident in HBM without linking
  * the HIP runtime themselves. */
@@ -271,21 +266,6 @@ MMDX_API mmdx_status mmdx_memcpy_h2d(void *dst_device, const void *src_host, siz
 MMDX_API mmdx_status mmdx_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
 MMDX_API mmdx_status mmdx_device_memset(void *dst_device, int value, size_t bytes);
 MMDX_API mmdx_status mmdx_device_synchronize(void);
-/* The launch-shape overrides for A/B runs (environment variables MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET,
- * MMDX_INTERLEAVE; tools/ab.py) are read once per process; this re-reads them.  Not for product use. */
-MMDX_API void mmdx_debug_reload_env(void);
-/* Device-to-device streaming copy / fill timed with HIP events: the practical HBM ceiling printed
- * next to the roofline.  bytes_moved = 2*bytes for copy, bytes for fill. */
-MMDX_API mmdx_status mmdx_bench_copy(void *dst_device, const void *src_device, size_t bytes,
-                                     int32_t iterations, float *avg_ms);
-MMDX_API mmdx_status mmdx_bench_fill(void *dst_device, size_t bytes, int32_t iterations,
-                                     float *avg_ms);
-/* Store-only replay of the crowd kernel's SoA output pattern (two arrays of n_instances x
- * n_vertices x 12 bytes, 6 KiB pieces): the write ceiling of THAT pattern on this box. */
-MMDX_API mmdx_status mmdx_bench_store_pattern(void *out_a_device, void *out_b_device,
-                                              uint32_t n_vertices, uint32_t n_instances,
-                                              int32_t iterations, float *avg_ms);
-
 /* Placement-aware allocation of a crowd's output arrays ([n_instances][NV] in `out_layout`; out_b stays
  * NULL for MMDX_OUT_VERTEX32).  On MI355X the store rate of the crowd's output pattern is bimodal in WHERE
  * the driver places the arrays (same virtual addresses, different physical backing: ~0.97 or ~0.75 of the

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMDX_LIB") or os.path.join(HERE, "libmmdx.so")   # MMDX_LIB: A/B of builds (tools/)
 
 OK = 0
+ABI_VERSION = 2          # include/mmdx.h MMDX_ABI_VERSION
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5: "OUT_OF_MEMORY",
              6: "UNSUPPORTED"}
 
@@ -60,7 +61,7 @@ class MmdxError(RuntimeError):
         self.status = status
 
 
-# every entry point include/mmdx.h declares: name -> (restype, argtypes)
+# every entry point include/mmdx.h and include/mmdx_bench.h declare: name -> (restype, argtypes)
 SIGNATURES = {
     "mmdx_abi_version": (C.c_uint32, []),
     "mmdx_last_error_string": (C.c_char_p, []),
@@ -152,7 +153,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.mmdx_abi_version() != 1:
+        if l.mmdx_abi_version() != ABI_VERSION:
             raise RuntimeError("libmmdx.so ABI version mismatch")
         _lib = l
     return _lib

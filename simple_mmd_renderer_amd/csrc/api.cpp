@@ -14,10 +14,13 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mmdx.h"
+#include "../../include/mmdx_bench.h"
 #include "error.hpp"
+#include "graph_pin.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
 #include "rig_kernels.hpp"
@@ -38,6 +41,14 @@ hipError_t g_prepare_status[16];
 mmdx_status hip_fail(hipError_t e, const char *what) {
     // leave no sticky error behind for the next call
     (void)hipGetLastError();
+    // the two refusals of DevBuf::ensure / rig_api's Buf::ensure (no HIP call failed)
+    if (e == hipErrorIllegalState)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, std::string(what) + ": a scratch buffer of this handle would have to grow, but a recorded "
+                    "graph (mmdx_graph_*) holds its address -- destroy the graph first, or size the buffers with an un-recorded call of "
+                    "the largest shape before recording");
+    if (e == hipErrorStreamCaptureUnsupported)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, std::string(what) + ": this call would have to allocate device memory while a graph is "
+                    "being recorded -- run the same sequence once un-recorded first");
     return fail(e == hipErrorOutOfMemory ? MMDX_ERR_OUT_OF_MEMORY
                                          : (e == hipErrorNoDevice ? MMDX_ERR_NO_DEVICE : MMDX_ERR_HIP),
                 std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")");
@@ -49,14 +60,18 @@ mmdx_status hip_fail(hipError_t e, const char *what) {
         if (e_ != hipSuccess) return hip_fail(e_, #expr);      \
     } while (0)
 
-thread_local bool tl_recording = false;   // a stream of this thread is recording a graph: nothing may allocate
+// Streams of this thread that are recording a graph (hipStreamCaptureModeThreadLocal: begin and end happen on one thread,
+// mmdx_graph_end enforces it): while > 0 nothing on this thread may allocate, copy from the host or wait.
+thread_local int tl_recording_depth = 0;
 
 struct DevBuf {
     void *ptr = nullptr;
     size_t bytes = 0;
+    const GraphPin *pin = nullptr;           // per-call scratch of a handle: may not move while a recorded graph holds it
     hipError_t ensure(size_t need) {
         if (need <= bytes) return hipSuccess;
-        if (tl_recording) return hipErrorStreamCaptureUnsupported;   // run the sequence once un-captured first
+        if (tl_recording_depth > 0) return hipErrorStreamCaptureUnsupported;   // run the sequence once un-captured first
+        if (graph_pinned(pin)) return hipErrorIllegalState;
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr; bytes = 0;
         hipError_t e = hipMalloc(&ptr, need);
@@ -101,6 +116,12 @@ struct mmdx_model_s {
     DevBuf pal, rates, wslot, morphed, out_a, out_b;
     bool morphed_valid = false;     // `morphed` holds the result of a shared morph pass (MMDX_MORPH_UNCHANGED)
     bool capturing = false;         // between mmdx_graph_begin and mmdx_graph_end: the stream records
+    std::thread::id capture_thread; // ... begun on this thread (thread-local capture mode: it must end there too)
+    GraphPin pin;                   // graphs that hold addresses of this model's scratch buffers
+    std::vector<GraphPin *> rec_pins;   // handles that took part in the recording in progress (incl. this model)
+    mmdx_model_s() {
+        for (DevBuf *b : {&pal, &rates, &wslot, &morphed, &out_a, &out_b}) b->pin = &pin;
+    }
     // page-locked bounce buffer for small outputs bound for pageable host memory (see mmdx_deform_batched)
     void *bounce = nullptr, *bounce_dev = nullptr;  // host address, device-side address
     size_t bounce_bytes = 0;
@@ -111,7 +132,26 @@ struct mmdx_graph_s {
     void *exec = nullptr;      // hipGraphExec_t
     void *stream = nullptr;    // the model's stream at recording time
     int device = 0;
+    std::atomic<bool> valid{true};        // false once a handle it was recorded from has been destroyed
+    std::vector<GraphPin *> pins;         // those handles (guarded by g_graph_mu)
 };
+
+namespace {
+std::mutex g_graph_mu;          // graph <-> handle links (rare operations: record, destroy)
+}
+void mmdx::graph_note_handle(mmdx_model_s *model, GraphPin *pin) {
+    if (!model || !model->capturing || !pin) return;
+    if (std::find(model->rec_pins.begin(), model->rec_pins.end(), pin) == model->rec_pins.end()) model->rec_pins.push_back(pin);
+}
+void mmdx::graph_drop_handle(GraphPin *pin) {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (mmdx_graph_s *g : pin->graphs) {
+        g->valid.store(false, std::memory_order_release);
+        g->pins.erase(std::remove(g->pins.begin(), g->pins.end(), pin), g->pins.end());
+    }
+    pin->graphs.clear();
+    pin->pins.store(0, std::memory_order_release);
+}
 
 namespace {
 
@@ -187,11 +227,13 @@ struct LaunchOverrides {
     int frame_threads;
     int shared_fused;   // MMDX_SHARED_FUSED: crowds with a shared facial state gather the morphs inside the deform kernel: 0 never,
                         // 1 up to 8 instances (default), 2 always (A/B, tests)
+    int xcd_chunk;      // MMDX_XCD_CHUNK: tiles per chunk of an XCD's tile range (kernels.hip map_workgroup); 0 = the call form's default
 };
 LaunchOverrides read_launch_overrides() {
     return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
             env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
-            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1)};
+            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1),
+            env_int("MMDX_XCD_CHUNK", 0)};
 }
 LaunchOverrides &launch_overrides() {
     static LaunchOverrides o = read_launch_overrides();
@@ -225,6 +267,7 @@ mmdx_status upload_model(mmdx_model_s *m) {
 }
 
 void free_model(mmdx_model_s *m) {
+    graph_drop_handle(&m->pin);              // graphs recorded from this model hold addresses that are about to be freed
     if (m->device >= 0) {
         (void)hipSetDevice(m->device);
         for (DevBuf *b : {&m->tiles, &m->spos, &m->snrm, &m->suv, &m->perm, &m->skin1, &m->skin2_ids,
@@ -252,6 +295,7 @@ size_t out_bytes_b(uint32_t layout, uint64_t nvi) {
 }  // namespace
 
 void mmdx::morph_motion_release_device(MorphMotionDevice &d) {
+    graph_drop_handle(&d.pin);               // graphs that hold these addresses can no longer be replayed
     if (d.device >= 0) (void)hipSetDevice(d.device);
     for (void **p : {&d.key_off, &d.frames, &d.weights, &d.frames_in, &d.out}) {
         if (*p) (void)hipFree(*p);
@@ -272,7 +316,7 @@ mmdx_status mmdx::resolve_stream(mmdx_model_t model, int *device, hipStream_t *s
     return MMDX_OK;
 }
 mmdx_status mmdx::hip_status(hipError_t e, const char *what) { return hip_fail(e, what); }
-bool mmdx::graph_recording() { return tl_recording; }
+bool mmdx::graph_recording() { return tl_recording_depth > 0; }
 
 // The wait at the end of a call that hands results back to the host.  A per-frame call is tens of
 // microseconds of device work; hipStreamSynchronize may put the thread to sleep and then pays a wake-up that is
@@ -331,6 +375,10 @@ mmdx_status mmdx_device_name(int32_t ordinal, char *buf, size_t buf_size) {
 mmdx_status mmdx_model_create(const mmdx_model_desc *desc, mmdx_model_t *out_model) {
     if (!desc || !out_model) return fail(MMDX_ERR_INVALID_ARGUMENT, "desc / out_model is NULL");
     *out_model = nullptr;
+    if (desc->struct_size == sizeof(mmdx_model_desc) &&
+        (desc->flags & ~uint32_t(MMDX_CREATE_NORMALIZE | MMDX_CREATE_HOST_ONLY | MMDX_CREATE_F16_POSITIONS | MMDX_CREATE_FAST_MATH |
+                                 MMDX_CREATE_TILE_ORDER)))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown bits in mmdx_model_desc.flags");
     mmdx_model_s *m = new (std::nothrow) mmdx_model_s;
     if (!m) return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed");
     std::string err;
@@ -448,6 +496,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     const Plan &p = m->plan;
     const uint32_t ni = a->n_instances, layout = a->out_layout;
     if (ni == 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "n_instances must be >= 1");
+    if (a->flags & ~uint32_t(MMDX_PALETTE_ON_DEVICE | MMDX_WEIGHTS_ON_DEVICE | MMDX_OUT_ON_DEVICE | MMDX_WEIGHTS_SHARED | MMDX_MORPH_UNCHANGED))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown bits in mmdx_deform_args.flags");
     if (layout > MMDX_OUT_SOA_POS16) return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown out_layout");
     if (p.f16 != (layout == MMDX_OUT_SOA_POS16))
         return fail(MMDX_ERR_UNSUPPORTED, "MMDX_OUT_SOA_POS16 goes with MMDX_CREATE_F16_POSITIONS models "
@@ -569,6 +619,9 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         } else if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
             HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, &f, st));      // flatten fused in: one launch
         } else if (morph == kMorphFused1) {
+            // A single frame (ni == 1) leaves the model's kept positions alone: they belong to the last SHARED CROWD call
+            // (MMDX_MORPH_UNCHANGED is documented against that one), whichever kernel the frame takes.
+            if (ni == 1) dp.morphed = nullptr;
             dp.fused_rates = rates_dev;                           // flatten inside the deform kernel
             dp.slot_top = f.slot_top; dp.chain_off = f.chain_off; dp.chain_rate = f.chain_rate;
             dp.nm = p.nm;
@@ -659,6 +712,16 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (forced > 0) group = std::max(uint32_t(forced) / gmin * gmin, gmin);
     }
     dp.group = group;
+    // Which workgroups of an XCD run side by side (map_workgroup): the crowd kernels take all of the XCD's tiles for one instance
+    // group after the other (0 = no chunking); the per-instance-morph kernels walk their tiles' morph-table slices once per pack of
+    // instances, so they keep FEW tiles x ALL their groups resident together (~64 workgroups per XCD: 2 per CU), and a slice is
+    // fetched into the XCD's L2 once instead of once per group.
+    dp.xcd_chunk = 0;
+    if (morph == kMorphFused4) {
+        const uint32_t ngroups = (ni + group - 1) / group;
+        dp.xcd_chunk = std::max(1u, 64u / std::max(ngroups, 1u));
+    }
+    if (ov.xcd_chunk > 0) dp.xcd_chunk = uint32_t(ov.xcd_chunk);
     const size_t lds = deform_lds_bytes(threads, layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off, dp.tile_order != 0);
     if (lds > 160 * 1024)
         return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(lds) + " bytes of LDS (> 160 KiB): "
@@ -790,7 +853,7 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
                                    const uint32_t *frames, uint32_t flags, float *out_weights) {
     if (!mm || !frames || !out_weights || !n_instances)
         return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
-    if (tl_recording && (flags & (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE)) != (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE))
+    if (tl_recording_depth > 0 && (flags & (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE)) != (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory");
     const MorphMotionHost h = morph_motion_host(mm);
     MorphMotionDevice &d = morph_motion_device(mm);
@@ -801,7 +864,8 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = model && model->device >= 0 ? model->stream : nullptr;
     if (d.device != device) {
-        if (tl_recording) return fail(MMDX_ERR_INVALID_ARGUMENT, "first use of this motion on the device: run the sequence once before recording it");
+        if (tl_recording_depth > 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "first use of this motion on the device: run the sequence once before recording it");
+        if (graph_pinned(&d.pin)) return fail(MMDX_ERR_INVALID_ARGUMENT, "this motion's device tables are held by a recorded graph: destroy the graph before moving it to another device");
         morph_motion_release_device(d);
         HIP_TRY(hipMalloc(&d.key_off, (size_t(h.nm) + 1) * 4));
         HIP_TRY(hipMalloc(&d.frames, std::max<size_t>(size_t(h.nkeys) * 4, 16)));
@@ -813,6 +877,7 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
         }
         d.device = device;
     }
+    graph_note_handle(model, &d.pin);
     MorphTrackParams t;
     t.key_off = static_cast<const uint32_t *>(d.key_off);
     t.key_frames = static_cast<const uint32_t *>(d.frames);
@@ -822,6 +887,7 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
         t.frames = frames;
     } else {
         if (d.frames_in_bytes < size_t(n_instances) * 4) {
+            if (graph_pinned(&d.pin)) return hip_fail(hipErrorIllegalState, "morph motion frame scratch");
             if (d.frames_in) (void)hipFree(d.frames_in);
             d.frames_in = nullptr; d.frames_in_bytes = 0;
             HIP_TRY(hipMalloc(&d.frames_in, size_t(n_instances) * 4));
@@ -835,6 +901,7 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
         t.out = out_weights;
     } else {
         if (d.out_bytes < out_bytes) {
+            if (graph_pinned(&d.pin)) return hip_fail(hipErrorIllegalState, "morph motion output scratch");
             if (d.out) (void)hipFree(d.out);
             d.out = nullptr; d.out_bytes = 0;
             HIP_TRY(hipMalloc(&d.out, std::max<size_t>(out_bytes, 16)));
@@ -860,7 +927,9 @@ mmdx_status mmdx_graph_begin(mmdx_model_t m) {
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
     m->capturing = true;
-    tl_recording = true;
+    m->capture_thread = std::this_thread::get_id();
+    m->rec_pins.assign(1, &m->pin);
+    ++tl_recording_depth;
     return MMDX_OK;
 }
 
@@ -868,8 +937,12 @@ mmdx_status mmdx_graph_end(mmdx_model_t m, mmdx_graph_t *out) {
     if (!m || !out) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
     if (!m->capturing) return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_graph_end without mmdx_graph_begin");
+    // thread-local capture mode: the runtime wants the end on the thread that began, and the per-thread recording
+    // state lives there -- refuse before anything is touched, so that the right thread can still end it
+    if (m->capture_thread != std::this_thread::get_id())
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_graph_end must be called on the thread that called mmdx_graph_begin");
     m->capturing = false;
-    tl_recording = false;
+    --tl_recording_depth;
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(m->stream, &g);
     if (e != hipSuccess || !g) return hip_fail(e != hipSuccess ? e : hipErrorUnknown, "hipStreamEndCapture (a recorded call failed?)");
@@ -880,12 +953,24 @@ mmdx_status mmdx_graph_end(mmdx_model_t m, mmdx_graph_t *out) {
     mmdx_graph_s *gr = new (std::nothrow) mmdx_graph_s;
     if (!gr) { (void)hipGraphExecDestroy(exec); return fail(MMDX_ERR_OUT_OF_MEMORY, "host allocation failed"); }
     gr->exec = exec; gr->stream = m->stream; gr->device = m->device;
+    {   // pin every handle whose buffers the recorded calls referred to
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        gr->pins = m->rec_pins;
+        for (GraphPin *p : gr->pins) {
+            p->graphs.push_back(gr);
+            p->pins.fetch_add(1, std::memory_order_acq_rel);
+        }
+    }
+    m->rec_pins.clear();
     *out = gr;
     return MMDX_OK;
 }
 
 mmdx_status mmdx_graph_launch(mmdx_graph_t g) {
     if (!g) return fail(MMDX_ERR_INVALID_ARGUMENT, "graph is NULL");
+    if (!g->valid.load(std::memory_order_acquire))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "a model, skeleton or motion this graph was recorded from has been destroyed: "
+                                               "the graph holds freed device addresses and cannot be replayed");
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(g->exec), static_cast<hipStream_t>(g->stream)));
     return MMDX_OK;
@@ -893,6 +978,14 @@ mmdx_status mmdx_graph_launch(mmdx_graph_t g) {
 
 void mmdx_graph_destroy(mmdx_graph_t g) {
     if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        for (GraphPin *p : g->pins) {
+            p->graphs.erase(std::remove(p->graphs.begin(), p->graphs.end(), g), p->graphs.end());
+            p->pins.fetch_sub(1, std::memory_order_acq_rel);
+        }
+        g->pins.clear();
+    }
     (void)hipSetDevice(g->device);
     (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g->exec));
     delete g;

@@ -62,6 +62,34 @@ __device__ __forceinline__ unsigned short f2h(float x) {
     return __builtin_bit_cast(unsigned short, _Float16(x));  // v_cvt_f16_f32, round to nearest even
 }
 
+// ---- cache policy of the OUTPUT stores (build-time A/B knob, tools/probes/store_policy_ab.py) --------------------------------
+// 98.7 % of the crowd kernel's HBM bytes are write-once stores.  MMDX_STORE_POLICY: 0 plain (the line stays in the XCD's L2
+// until evicted), 1 `nt` (non-temporal hint), 2 `sc1`, 3 `sc0 sc1` (write-through: the line is dropped from L2) --
+// MI355X_MICROARCH.md, "stores of each flavour".  The shipped value is the one that measured best.
+#ifndef MMDX_STORE_POLICY
+#define MMDX_STORE_POLICY 0
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(float4 *dst, const float4 v) {
+#if MMDX_STORE_POLICY == 1
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(dst));
+#elif MMDX_STORE_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
+#elif MMDX_STORE_POLICY == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
+#else
+    *dst = v;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void store_elem(T *dst, const T v) {      // scalar pieces (ragged tiles, direct stores)
+#if MMDX_STORE_POLICY == 1
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;           // (scalar sc1 stores are one fabric write each -- the guide prices a dword at 6x a dwordx4 per byte: never)
+#endif
+}
+
 // ---- matrix blend + mat*vec, reference operation order, on PACKED f32 pairs ------------------------
 // A wave64 issues one VALU instruction per 4 cycles, so at the occupancy this kernel runs at the
 // number of VALU instructions is what counts: v_pk_mul_f32 / v_pk_add_f32 do two IEEE f32 operations
@@ -132,13 +160,13 @@ __device__ __forceinline__ void copy_chunk(const unsigned char *img, T *g, uint3
     const uint32_t lo = q * EPC;
     if (aligned16 && lo >= shift && lo + EPC <= shift + n) {
         const float4 v = *reinterpret_cast<const float4 *>(img + size_t(q) * 16);
-        *reinterpret_cast<float4 *>(g + lo) = v;
+        store16(reinterpret_cast<float4 *>(g + lo), v);
     } else {
         const T *l = reinterpret_cast<const T *>(img);
 #pragma unroll
         for (uint32_t e = 0; e < EPC; ++e) {
             const uint32_t i = lo + e;
-            if (i >= shift && i < shift + n) g[i] = l[i];
+            if (i >= shift && i < shift + n) store_elem(g + i, l[i]);
         }
     }
 }
@@ -183,7 +211,7 @@ struct CopyFast {
             CopyFast<THREADS, CA, CB, I + 1>::run(img, gapB, outA, outB, tid);
             if (full || q < TOTAL) {
                 float4 *dst = inA ? outA + q : outB + (q - CA);
-                *dst = v;
+                store16(dst, v);
             }
         }
     }
@@ -307,8 +335,22 @@ __device__ __forceinline__ bool map_workgroup(const DeformParams &p, uint32_t &t
     const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
     const uint32_t T = p.ntiles >> 3, main_count = T * p.ngroups;
     if (k < main_count) {
-        grp = k / T;
-        tile = xcd * T + (k - grp * T);
+        // An XCD's T tiles are walked in CHUNKS of p.xcd_chunk tiles: inside a chunk tile index fastest, then the instance
+        // groups, then the next chunk.  xcd_chunk = T (the crowd kernels): all tiles of group 0, then of group 1, ...  A small
+        // chunk (the per-instance-morph kernels) keeps the workgroups that are resident together on FEW tiles x MANY groups,
+        // so that the tiles' morph-table slices are fetched into the XCD's L2 once instead of once per group (config 5 x 64
+        // frames: 64 tiles x 82 KB per XCD = 5.2 MB do not fit the 4 MB L2, and the table was re-read for every group).
+        const uint32_t C = p.xcd_chunk, per = C * p.ngroups, c = k / per;
+        const uint32_t full = T / C;
+        if (c < full) {
+            const uint32_t w = k - c * per;
+            grp = w / C;
+            tile = xcd * T + c * C + (w - grp * C);
+        } else {
+            const uint32_t rest = T - full * C, w = k - full * per;
+            grp = w / rest;
+            tile = xcd * T + full * C + (w - grp * rest);
+        }
         return true;
     }
     const uint32_t r = xcd * p.rem_per_xcd + (k - main_count);
@@ -569,8 +611,8 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
             } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
                 float *A = reinterpret_cast<float *>(p.out_a) + v * 8;
                 if (al) {
-                    reinterpret_cast<float4 *>(A)[0] = make_float4(oxy.x, oxy.y, oz, rxy.x);
-                    reinterpret_cast<float4 *>(A)[1] = make_float4(rxy.y, rz, q.uv.x, q.uv.y);
+                    store16(reinterpret_cast<float4 *>(A), make_float4(oxy.x, oxy.y, oz, rxy.x));
+                    store16(reinterpret_cast<float4 *>(A) + 1, make_float4(rxy.y, rz, q.uv.x, q.uv.y));
                 } else {
                     A[0] = oxy.x; A[1] = oxy.y; A[2] = oz; A[3] = rxy.x; A[4] = rxy.y; A[5] = rz; A[6] = q.uv.x; A[7] = q.uv.y;
                 }
@@ -804,7 +846,10 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             }
             if (more) {
                 // every wave has left this pack's walk (it passed the barriers of the pack's instances): the weights can
-                // be replaced; one barrier before the next walk reads them
+                // be replaced; one barrier before the next walk reads them.  Tile-order outputs have no per-instance barrier
+                // (skin_instance returns before it), so there a wave with short morph rows could get here while another is
+                // still reading this pack's weights: one barrier per pack closes the walk explicitly.
+                if constexpr (TILE) __syncthreads();
                 if (wreg) {
                     if (uint32_t(tid) < wcount) wq[tid] = wnext;
                 } else {
@@ -1110,6 +1155,8 @@ hipError_t MMDX_K(launch_deform)(int threads, int layout, int morph, bool f16, c
     q.ntiles = ntiles;
     q.ngroups = (p.ni + p.group - 1) / p.group;
     q.rem_per_xcd = ((ntiles & 7u) * q.ngroups + 7u) / 8u;
+    const uint32_t T = ntiles >> 3;
+    q.xcd_chunk = (p.xcd_chunk == 0 || p.xcd_chunk > T) ? (T ? T : 1u) : p.xcd_chunk;
     const dim3 grid(8u * ((ntiles >> 3) * q.ngroups + q.rem_per_xcd));
     hipLaunchKernelGGL(fn, grid, dim3((threads == 256 || kTileVerts < 512) ? 256 : 512), lds_bytes, stream, q);
     return hipGetLastError();

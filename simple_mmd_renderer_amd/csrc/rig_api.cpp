@@ -11,6 +11,7 @@
 
 #include "../../include/mmdx.h"
 #include "error.hpp"
+#include "graph_pin.hpp"
 #include "rig.hpp"
 #include "rig_kernels.hpp"
 #include "vmd.hpp"
@@ -28,10 +29,12 @@ namespace {
 struct Buf {
     void *ptr = nullptr;
     size_t bytes = 0;
+    const GraphPin *pin = nullptr;           // the owning handle's: a buffer a recorded graph holds may not move
     hipError_t ensure(size_t need) {
         need = std::max<size_t>(need, 16);
         if (need <= bytes) return hipSuccess;
         if (graph_recording()) return hipErrorStreamCaptureUnsupported;   // run the sequence once un-captured first
+        if (graph_pinned(pin)) return hipErrorIllegalState;                 // (hip_status turns both into a clear message)
         release();
         hipError_t e = hipMalloc(&ptr, need);
         if (e == hipSuccess) bytes = need;
@@ -55,6 +58,10 @@ struct mmdx_bone_motion_s {
     BoneMotionHost host;
     int device = -1;
     Buf key_off, key_frame, key_tr, key_rot, key_curve, lut, frames_in, out;
+    GraphPin pin;                                         // recorded graphs that hold these buffers' addresses
+    mmdx_bone_motion_s() {
+        for (Buf *b : {&key_off, &key_frame, &key_tr, &key_rot, &key_curve, &lut, &frames_in, &out}) b->pin = &pin;
+    }
 };
 
 struct mmdx_skeleton_s {
@@ -67,6 +74,12 @@ struct mmdx_skeleton_s {
     uint32_t pre_instances = 0;                           // instances of the last mmdx_skeleton_solve_pre (0: none pending)
     const float *pre_poses = nullptr;                     // the poses that call solved (device address)
     const float *pre_morph = nullptr;
+    GraphPin pin;                                         // recorded graphs that hold these buffers' addresses
+    mmdx_skeleton_s() {
+        for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &events, &rounds,
+                       &state, &apps, &app_chain, &rates_in, &morph_state, &over_bone, &over_strict, &over_skin})
+            b->pin = &pin;
+    }
     void release_all() {
         for (Buf *b : {&local_offset, &neg_rest, &chain_off, &chain, &poses_in, &out, &order, &bones, &iks, &links, &events, &rounds,
                        &state,
@@ -78,6 +91,7 @@ struct mmdx_skeleton_s {
 // static tables of a motion / a skeleton -> the device they are about to run on (once per device)
 static mmdx_status motion_to_device(mmdx_bone_motion_t m, int device) {
     if (m->device == device) return MMDX_OK;
+    if (graph_pinned(&m->pin)) return hip_status(hipErrorIllegalState, "moving a bone motion to another device");
     const BoneMotionHost &h = m->host;
     for (Buf *b : {&m->key_off, &m->key_frame, &m->key_tr, &m->key_rot, &m->key_curve, &m->lut, &m->frames_in, &m->out})
         b->release();
@@ -104,6 +118,7 @@ static BoneTrackParams motion_params(mmdx_bone_motion_t m, uint32_t n_instances)
 }
 static mmdx_status skeleton_to_device(mmdx_skeleton_t s, int device) {
     if (s->device == device) return MMDX_OK;
+    if (graph_pinned(&s->pin)) return hip_status(hipErrorIllegalState, "moving a skeleton to another device");
     const SkeletonPlan &pl = s->plan;
     s->release_all();
     HIP_TRY(s->apps.upload(pl.apps));
@@ -169,6 +184,7 @@ mmdx_status mmdx_bone_motion_eval(mmdx_bone_motion_t m, mmdx_model_t model, uint
         return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory and the "
                                                "motion must have run on this device before");
     if (mmdx_status r = motion_to_device(m, device)) return r;
+    graph_note_handle(model, &m->pin);
     BoneTrackParams p = motion_params(m, n_instances);
     if (flags & MMDX_FRAMES_ON_DEVICE) {
         p.frames = frames;
@@ -196,6 +212,7 @@ mmdx_status mmdx_bone_motion_eval(mmdx_bone_motion_t m, mmdx_model_t model, uint
 
 void mmdx_bone_motion_destroy(mmdx_bone_motion_t m) {
     if (!m) return;
+    graph_drop_handle(&m->pin);
     if (m->device >= 0) (void)hipSetDevice(m->device);
     for (Buf *b : {&m->key_off, &m->key_frame, &m->key_tr, &m->key_rot, &m->key_curve, &m->lut, &m->frames_in,
                    &m->out})
@@ -265,6 +282,8 @@ mmdx_status mmdx_skeleton_solve_motion(mmdx_skeleton_t s, mmdx_bone_motion_t m, 
                                                "and the skeleton must have run on this device before");
     if (mmdx_status r = motion_to_device(m, device)) return r;
     if (mmdx_status r = skeleton_to_device(s, device)) return r;
+    graph_note_handle(model, &m->pin);
+    graph_note_handle(model, &s->pin);
     BoneTrackParams tp = motion_params(m, n_instances);
     if (flags & MMDX_FRAMES_ON_DEVICE) {
         tp.frames = frames;
@@ -354,6 +373,7 @@ static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_
                                                    "(host lists) are not recordable");
     }
     if (mmdx_status r = skeleton_to_device(s, device)) return r;
+    graph_note_handle(model, &s->pin);
     struct { const float *poses; float *out; } p;
     const size_t in_bytes = size_t(n_instances) * pl.nb * MMDX_POSE_FLOATS * sizeof(float);
     const size_t out_bytes = size_t(n_instances) * pl.nb * 16 * sizeof(float);
@@ -466,6 +486,7 @@ static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_
 
 extern "C" void mmdx_skeleton_destroy(mmdx_skeleton_t s) {
     if (!s) return;
+    graph_drop_handle(&s->pin);
     if (s->device >= 0) (void)hipSetDevice(s->device);
     s->release_all();
     delete s;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/mmdx.h"
+#include "graph_pin.hpp"
 
 namespace mmdx {
 
@@ -23,6 +24,7 @@ struct MorphMotionDevice {        // owned by api.cpp (hipMalloc / hipFree)
     void *frames_in = nullptr, *out = nullptr;   // per-call scratch for host-pointer callers
     size_t frames_in_bytes = 0, out_bytes = 0;
     int device = -1;
+    GraphPin pin;                 // recorded graphs that hold these addresses
 };
 
 const MorphMotionHost morph_motion_host(const mmdx_morph_motion_s *m);

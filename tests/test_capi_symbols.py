@@ -10,12 +10,21 @@ import pytest
 from simple_mmd_renderer_amd import _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "mmdx.h")
+HEADER = os.path.join(ROOT, "include", "mmdx.h")                 # the drop-in boundary
+BENCH_HEADER = os.path.join(ROOT, "include", "mmdx_bench.h")     # timers / ceilings / A-B knobs: not the boundary
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+def declared_symbols(headers=(HEADER, BENCH_HEADER)):
+    text = "".join(open(h).read() for h in headers)
     return sorted(set(re.findall(r"MMDX_API\s+[\w\s\*]+?\b(mmdx_\w+)\s*\(", text)))
+
+
+def test_boundary_header_carries_no_bench_or_debug_entry_points():
+    syms = declared_symbols((HEADER,))
+    assert not [s for s in syms if s.startswith(("mmdx_bench_", "mmdx_debug_", "mmdx_timer_", "mmdx_profile_"))]
+    assert set(declared_symbols((BENCH_HEADER,))) == {
+        "mmdx_timer_start", "mmdx_timer_stop", "mmdx_profile_enable", "mmdx_profile_collect", "mmdx_debug_reload_env",
+        "mmdx_bench_copy", "mmdx_bench_fill", "mmdx_bench_store_pattern"}
 
 
 def test_header_declares_the_path():
@@ -28,7 +37,7 @@ def test_header_declares_the_path():
 
 def test_library_exports_every_declared_symbol(hip_lib):
     for name in declared_symbols():
-        assert hasattr(hip_lib, name), f"{name} declared in mmdx.h but not exported by libmmdx.so"
+        assert hasattr(hip_lib, name), f"{name} declared in include/*.h but not exported by libmmdx.so"
     # and the Python binding covers exactly the header
     assert sorted(_capi.SIGNATURES) == declared_symbols()
 
@@ -47,7 +56,7 @@ def test_struct_sizes_match_header():
 
 
 def test_abi_version_and_error_string(hip_lib):
-    assert hip_lib.mmdx_abi_version() == 1
+    assert hip_lib.mmdx_abi_version() == 2
     st = hip_lib.mmdx_model_create(None, None)
     assert st == 1
     assert b"NULL" in hip_lib.mmdx_last_error_string()

@@ -575,6 +575,64 @@ def test_config3_crowd_every_instance_vs_oracle(oracle):
         d_a.free(); d_b.free()
 
 
+def test_config3_crowd_vertex32_full_size_bench_call_form(oracle):
+    """BASELINE config 3 with the viewer's interleaved 32-byte vertex as output (Deform + UpdateDeformedVertices in one kernel,
+    main.cpp:838-859), in EXACTLY the call form bench.py times as `config3_vertex32_output`: 1024 instances, shared rates of
+    frame 30, palettes (i*3) % 1801, pos_scale 0.1, output array from mmdx_crowd_output_alloc, profiling events on.  A 72-instance
+    sample (every 16th instance plus the first and last groups), every vertex, bit for bit against oracle.repack32."""
+    m = synth.make_config("config3_crowd")
+    ni = 1024
+    pals = synth.make_palettes(m, (np.arange(ni) * 3) % 1801)
+    rates = synth.morph_weights(m.nm, 30)[0]
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    with DeformModel(m) as dm:
+        d_w, d_pal = DeviceBuffer.from_numpy(rates), DeviceBuffer.from_numpy(pals)
+        d_v32, none_b, _pl = dm.alloc_outputs(api.OUT_VERTEX32, ni, 4)
+        assert none_b is None
+        d_v32.memset(0xFF)
+        dm.profile_enable(True)
+        for _ in range(2):
+            dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_v32.ptr, None, api.OUT_VERTEX32, flags, 0.1)
+        dm.profile_collect()
+        dm.profile_enable(False)
+        dm.sync()
+        skin = oracle.normalize(m)
+        vimg = oracle.morph(m, rates)
+        row = m.nv * 32
+        for i in sorted(set(range(0, ni, 16)) | set(range(4)) | set(range(ni - 4, ni))):
+            ep, en = oracle.skin(m, pals[i], vimg, skin)
+            gu.assert_bits_equal(d_v32.download((m.nv, 8), np.float32, offset=i * row), oracle.repack32(m, ep, en, 0.1),
+                                 f"crowd v32 inst {i}")
+        for b in (d_w, d_pal, d_v32):
+            b.free()
+
+
+def test_config3_bucketed_vertices_bench_call_form(oracle):
+    """bench.py's `config3_bucketed_vertices`: the config-3 model with its vertices pre-sorted by deform type inside each tile
+    (synth.presort_by_class), 1024-instance shared-morph crowd into arrays from mmdx_crowd_output_alloc -- a 40-instance sample,
+    every vertex, against the oracle run on the SORTED model."""
+    m = synth.presort_by_class(synth.make_config("config3_crowd"))
+    ni = 1024
+    pals = synth.make_palettes(m, (np.arange(ni) * 3) % 1801)
+    rates = synth.morph_weights(m.nm, 30)[0]
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    with DeformModel(m) as dm:
+        d_w, d_pal = DeviceBuffer.from_numpy(rates), DeviceBuffer.from_numpy(pals)
+        d_a, d_b, _pl = dm.alloc_outputs(api.OUT_SOA, ni, 4)
+        d_a.memset(0xFF); d_b.memset(0xFF)
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+        dm.sync()
+        skin = oracle.normalize(m)
+        vimg = oracle.morph(m, rates)
+        row = m.nv * 12
+        for i in sorted(set(range(0, ni, 32)) | set(range(4)) | set(range(ni - 4, ni))):
+            ep, en = oracle.skin(m, pals[i], vimg, skin)
+            gu.assert_bits_equal(d_a.download((m.nv, 3), np.float32, offset=i * row), ep, f"bucketed inst {i} pos")
+            gu.assert_bits_equal(d_b.download((m.nv, 3), np.float32, offset=i * row), en, f"bucketed inst {i} nrm")
+        for b in (d_w, d_pal, d_a, d_b):
+            b.free()
+
+
 def test_config3prime_per_instance_morph_crowd_sample(oracle):
     """Config 3' (every instance its own facial state, 1024 x 50k, fused gather): a strided sample of 64 instances
     plus the first and last packs of 8, every vertex against the oracle."""

@@ -28,7 +28,22 @@ def run(name, model, ni, frames, layout, iters, f16=False):
     sa, sb = dm.out_sizes(layout, ni)
     d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
-    ms = bench.time_calls(dm, lambda: dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, layout, flags), iters)
+    call = lambda: dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, layout, flags)   # noqa: E731
+    # FB_SWEEP="MMDX_XCD_CHUNK=0,1,2,4": one launch-shape override swept in this process (interleaved, FB_ROUNDS rounds, medians)
+    if os.environ.get("FB_SWEEP"):
+        knob, vals = os.environ["FB_SWEEP"].split("=")
+        res = {v: [] for v in vals.split(",")}
+        for r in range(int(os.environ.get("FB_ROUNDS", "5")) + 1):
+            for v in res:
+                os.environ[knob] = v
+                api.lib().mmdx_debug_reload_env()
+                t = bench.time_calls(dm, call, iters)
+                if r:
+                    res[v].append(t * 1e3)
+        os.environ.pop(knob, None)
+        api.lib().mmdx_debug_reload_env()
+        print(f"{name:8s} sweep {knob}: " + "  ".join(f"{v}: {np.median(t):.1f} us" for v, t in res.items()), flush=True)
+    ms = bench.time_calls(dm, call, iters)
     i = dm.info
     if f16:
         static = model.nv * (6 + 12 + 1) + i.n_bdef1 * 2 + i.n_bdef2 * 8 + i.n_bdef4 * 24
