@@ -537,3 +537,72 @@ class Reference:
         return float(self.lib.mmdref_time_crowd(self.h, C.c_uint32(pal.shape[0]),
                                                 _p(_c(rates, np.float32), C.c_float),
                                                 _p(pal, C.c_float)))
+
+
+# ---- the REAL physics reactor (libmmd's mmd-bullet binding + the vendored Bullet), oracle/ref_bullet_harness.cpp ------------
+BULLET_REF_SO = os.path.join(_HERE, "_ref", "libmmd_bullet_ref.so")
+
+
+def bullet_reference_available() -> bool:
+    return os.path.exists(BULLET_REF_SO)
+
+
+class BulletReference:
+    """mmd::Poser + mmd::BulletPhysicsReactor on a model with rigid bodies and 6-DOF spring constraints, stepped the way the
+    viewer's frame() does (main.cpp:1786-1821).  `rig` = dict(rest, parent, level, flags); `mesh` = dict(positions, normals,
+    skin_type, bone_ids, bone_weights); `bodies` / `joints` = dicts of the PMX rigid-body / joint fields (see
+    oracle/gen_golden_bullet.py)."""
+
+    def __init__(self, rig, mesh, bodies, joints):
+        if not bullet_reference_available():
+            raise RuntimeError("oracle/_ref/libmmd_bullet_ref.so not built (needs /root/reference)")
+        self.lib = C.CDLL(BULLET_REF_SO)
+        self.lib.mmdbt_create.restype = C.c_void_p
+        self.nb = int(np.asarray(rig["rest"]).shape[0])
+        self.nv = int(np.asarray(mesh["positions"]).shape[0])
+        self.nrb = int(np.asarray(bodies["bone"]).shape[0])
+        nc = int(np.asarray(joints["body"]).shape[0])
+        f32, i64 = np.float32, np.int64
+        a = [(_c(rig["rest"], f32), C.c_float), (_c(rig["parent"], i64), C.c_int64), (_c(rig["level"], np.int32), C.c_int32),
+             (_c(rig["flags"], np.uint16), C.c_uint16)]
+        b = [(_c(mesh["positions"], f32), C.c_float), (_c(mesh["normals"], f32), C.c_float),
+             (_c(mesh["skin_type"], np.int32), C.c_int32), (_c(mesh["bone_ids"], i64), C.c_int64),
+             (_c(mesh["bone_weights"], f32), C.c_float)]
+        c = [(_c(bodies["bone"], i64), C.c_int64), (_c(bodies["group"], np.uint8), C.c_uint8), (_c(bodies["mask"], np.uint16), C.c_uint16),
+             (_c(bodies["shape"], np.uint8), C.c_uint8), (_c(bodies["dims"], f32), C.c_float), (_c(bodies["pos"], f32), C.c_float),
+             (_c(bodies["rot"], f32), C.c_float), (_c(bodies["mass"], f32), C.c_float), (_c(bodies["tdamp"], f32), C.c_float),
+             (_c(bodies["rdamp"], f32), C.c_float), (_c(bodies["restitution"], f32), C.c_float), (_c(bodies["friction"], f32), C.c_float),
+             (_c(bodies["type"], np.uint8), C.c_uint8)]
+        d = [(_c(joints["body"], i64), C.c_int64)] + [(_c(joints[k], f32), C.c_float)
+                                                       for k in ("pos", "rot", "pos_lo", "pos_hi", "rot_lo", "rot_hi", "spring_t", "spring_r")]
+        self._keep = a + b + c + d
+        self.h = C.c_void_p(self.lib.mmdbt_create(
+            C.c_uint32(self.nb), *[_p(x, t) for x, t in a], C.c_uint32(self.nv), *[_p(x, t) for x, t in b],
+            C.c_uint32(self.nrb), *[_p(x, t) for x, t in c], C.c_uint32(nc), *[_p(x, t) for x, t in d]))
+
+    def body_info(self):
+        """(passive, strict, ghost) u8 [NRB] as PoserMotionState classified the bodies."""
+        out = [np.zeros(self.nrb, np.uint8) for _ in range(3)]
+        self.lib.mmdbt_body_info(self.h, *[_p(o, C.c_uint8) for o in out])
+        return out
+
+    def frame(self, poses, step=1.0 / 30.0):
+        """One viewer frame.  Returns dict(palette_pre [NB,16], body_xf [NRB,16], palette [NB,16], pos [NV,3], nrm [NV,3])."""
+        poses = _c(poses, np.float32).reshape(self.nb, 8)
+        o = dict(palette_pre=np.zeros((self.nb, 16), np.float32), body_xf=np.zeros((self.nrb, 16), np.float32),
+                 palette=np.zeros((self.nb, 16), np.float32), pos=np.zeros((self.nv, 3), np.float32),
+                 nrm=np.zeros((self.nv, 3), np.float32))
+        self.lib.mmdbt_frame(self.h, _p(poses, C.c_float), C.c_float(step), *[_p(o[k], C.c_float)
+                                                                             for k in ("palette_pre", "body_xf", "palette", "pos", "nrm")])
+        return o
+
+    def close(self):
+        if self.h:
+            self.lib.mmdbt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

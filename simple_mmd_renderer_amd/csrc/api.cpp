@@ -227,13 +227,11 @@ struct LaunchOverrides {
     int frame_threads;
     int shared_fused;   // MMDX_SHARED_FUSED: crowds with a shared facial state gather the morphs inside the deform kernel: 0 never,
                         // 1 up to 8 instances (default), 2 always (A/B, tests)
-    int xcd_chunk;      // MMDX_XCD_CHUNK: tiles per chunk of an XCD's tile range (kernels.hip map_workgroup); 0 = the call form's default
 };
 LaunchOverrides read_launch_overrides() {
     return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
             env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
-            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1),
-            env_int("MMDX_XCD_CHUNK", 0)};
+            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1)};
 }
 LaunchOverrides &launch_overrides() {
     static LaunchOverrides o = read_launch_overrides();
@@ -712,16 +710,6 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (forced > 0) group = std::max(uint32_t(forced) / gmin * gmin, gmin);
     }
     dp.group = group;
-    // Which workgroups of an XCD run side by side (map_workgroup): the crowd kernels take all of the XCD's tiles for one instance
-    // group after the other (0 = no chunking); the per-instance-morph kernels walk their tiles' morph-table slices once per pack of
-    // instances, so they keep FEW tiles x ALL their groups resident together (~64 workgroups per XCD: 2 per CU), and a slice is
-    // fetched into the XCD's L2 once instead of once per group.
-    dp.xcd_chunk = 0;
-    if (morph == kMorphFused4) {
-        const uint32_t ngroups = (ni + group - 1) / group;
-        dp.xcd_chunk = std::max(1u, 64u / std::max(ngroups, 1u));
-    }
-    if (ov.xcd_chunk > 0) dp.xcd_chunk = uint32_t(ov.xcd_chunk);
     const size_t lds = deform_lds_bytes(threads, layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off, dp.tile_order != 0);
     if (lds > 160 * 1024)
         return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(lds) + " bytes of LDS (> 160 KiB): "

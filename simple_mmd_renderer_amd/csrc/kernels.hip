@@ -64,10 +64,13 @@ __device__ __forceinline__ unsigned short f2h(float x) {
 
 // ---- cache policy of the OUTPUT stores (build-time A/B knob, tools/probes/store_policy_ab.py) --------------------------------
 // 98.7 % of the crowd kernel's HBM bytes are write-once stores.  MMDX_STORE_POLICY: 0 plain (the line stays in the XCD's L2
-// until evicted), 1 `nt` (non-temporal hint), 2 `sc1`, 3 `sc0 sc1` (write-through: the line is dropped from L2) --
-// MI355X_MICROARCH.md, "stores of each flavour".  The shipped value is the one that measured best.
+// until evicted), 1 `nt` (non-temporal hint), 2 `sc1`, 3 `sc0 sc1` (write-through: the line is dropped from L2), 4 `sc1 nt`,
+// 5 `sc0 nt` -- MI355X_MICROARCH.md, "stores of each flavour".  Shipped: 1.  Measured interleaved on the same arrays
+// (profiles/r03/store_policy_*.txt): nt takes the crowd kernel from 218.7 to 206.2 us (fast placement; 264 -> 253 on a slow
+// one), the 32-byte-vertex crowd from 271 to 246, config 3' from 382 to 341, config 5 x 64 from 144 to 136; sc1 / sc0 sc1 change
+// nothing on a fast placement and gain 3 % on a slow one.  Results are bit-identical under every policy.
 #ifndef MMDX_STORE_POLICY
-#define MMDX_STORE_POLICY 0
+#define MMDX_STORE_POLICY 1
 #endif
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(float4 *dst, const float4 v) {
@@ -77,8 +80,20 @@ __device__ __forceinline__ void store16(float4 *dst, const float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
 #elif MMDX_STORE_POLICY == 3
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
+#elif MMDX_STORE_POLICY == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
+#elif MMDX_STORE_POLICY == 5
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
 #else
     *dst = v;
+#endif
+}
+// three consecutive floats (tile-order direct stores: 12-byte vertices, so no 16-byte alignment to promise)
+__device__ __forceinline__ void store3(float *dst, float x, float y, float z) {
+#if MMDX_STORE_POLICY == 1
+    __builtin_nontemporal_store(x, dst); __builtin_nontemporal_store(y, dst + 1); __builtin_nontemporal_store(z, dst + 2);
+#else
+    dst[0] = x; dst[1] = y; dst[2] = z;
 #endif
 }
 template <typename T>
@@ -331,26 +346,15 @@ __device__ __forceinline__ float slot_weight(const float *rates, const uint32_t 
 // x (8 groups): a tile's static streams and the palette rows neighbouring tiles share are fetched
 // into that L2 once instead of once per XCD.  Tiles left over by ntiles % 8 are split by groups.
 // Returns false for a padding workgroup.
+// (Round 3 tried walking an XCD's tiles in CHUNKS -- few tiles x all their instance groups resident together, so that the
+// per-instance-morph kernels fetch a tile's morph-table slice into L2 once per launch instead of once per group: config 5 x 64
+// and config 2 x 64 unchanged within noise, config 3' 7 % slower at 1-2 tiles per chunk; profiles/r03/xcd_chunk_sweep.txt.)
 __device__ __forceinline__ bool map_workgroup(const DeformParams &p, uint32_t &tile, uint32_t &grp) {
     const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
     const uint32_t T = p.ntiles >> 3, main_count = T * p.ngroups;
     if (k < main_count) {
-        // An XCD's T tiles are walked in CHUNKS of p.xcd_chunk tiles: inside a chunk tile index fastest, then the instance
-        // groups, then the next chunk.  xcd_chunk = T (the crowd kernels): all tiles of group 0, then of group 1, ...  A small
-        // chunk (the per-instance-morph kernels) keeps the workgroups that are resident together on FEW tiles x MANY groups,
-        // so that the tiles' morph-table slices are fetched into the XCD's L2 once instead of once per group (config 5 x 64
-        // frames: 64 tiles x 82 KB per XCD = 5.2 MB do not fit the 4 MB L2, and the table was re-read for every group).
-        const uint32_t C = p.xcd_chunk, per = C * p.ngroups, c = k / per;
-        const uint32_t full = T / C;
-        if (c < full) {
-            const uint32_t w = k - c * per;
-            grp = w / C;
-            tile = xcd * T + c * C + (w - grp * C);
-        } else {
-            const uint32_t rest = T - full * C, w = k - full * per;
-            grp = w / rest;
-            tile = xcd * T + full * C + (w - grp * rest);
-        }
+        grp = k / T;
+        tile = xcd * T + (k - grp * T);
         return true;
     }
     const uint32_t r = xcd * p.rem_per_xcd + (k - main_count);
@@ -606,8 +610,8 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
             const size_t v = vbase + uint32_t(tid) + uint32_t(k) * THREADS;
             if constexpr (LAYOUT == MMDX_OUT_SOA) {
                 float *A = reinterpret_cast<float *>(p.out_a) + v * 3, *B = reinterpret_cast<float *>(p.out_b) + v * 3;
-                A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
-                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
+                store3(A, oxy.x, oxy.y, oz);
+                store3(B, rxy.x, rxy.y, rz);
             } else if constexpr (LAYOUT == MMDX_OUT_VERTEX32) {
                 float *A = reinterpret_cast<float *>(p.out_a) + v * 8;
                 if (al) {
@@ -1155,8 +1159,6 @@ hipError_t MMDX_K(launch_deform)(int threads, int layout, int morph, bool f16, c
     q.ntiles = ntiles;
     q.ngroups = (p.ni + p.group - 1) / p.group;
     q.rem_per_xcd = ((ntiles & 7u) * q.ngroups + 7u) / 8u;
-    const uint32_t T = ntiles >> 3;
-    q.xcd_chunk = (p.xcd_chunk == 0 || p.xcd_chunk > T) ? (T ? T : 1u) : p.xcd_chunk;
     const dim3 grid(8u * ((ntiles >> 3) * q.ngroups + q.rem_per_xcd));
     hipLaunchKernelGGL(fn, grid, dim3((threads == 256 || kTileVerts < 512) ? 256 : 512), lds_bytes, stream, q);
     return hipGetLastError();

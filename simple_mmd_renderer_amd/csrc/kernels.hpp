@@ -53,7 +53,6 @@ struct DeformParams {
     uint32_t nv, nb, ns, ni;
     uint32_t group;              // instances per workgroup (multiple of 4 for kMorphFused4)
     uint32_t ntiles, ngroups, rem_per_xcd;  // filled by launch_deform (XCD-aware work mapping)
-    uint32_t xcd_chunk;          // tiles per chunk of an XCD's tile range (0 = all of them; launch_deform clamps it)
     uint32_t pal_stride;         // float4 per instance in LDS (= max_tile_bones * 3)
     uint32_t stage_off;          // byte offsets inside dynamic LDS
     uint32_t w_off;
