@@ -81,7 +81,7 @@ def make_case(seed=77):
             J["spring_t"].append((0, 0, 0) if c != 1 else (10.0, 10.0, 10.0)); J["spring_r"].append((20.0 * (j % 2), 5.0, 12.0))
             prev_body = rb
     # a second body on a chain bone that already has one (listed later: its Synchronize wins), and a body on a post-physics bone
-    body(chains[2][1], 1, 0, (0.2, 0, 0), 4, off=(0.1, -0.2, 0.1), mass=0.3)
+    body(chains[2][2], 1, 0, (0.2, 0, 0), 4, off=(0.1, -0.2, 0.1), mass=0.3)
     body(posts[2], 1, 0, (0.25, 0, 0), 5, off=(0.0, -0.1, 0.0), mass=0.4)
     bodies = {k: np.asarray(v) for k, v in B.items()}
     joints = {k: np.asarray(v) for k, v in J.items()}

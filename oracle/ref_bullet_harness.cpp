@@ -19,6 +19,14 @@
 // The reactor keeps its motion states private; this file reads them (`#define private public` around the one libmmd
 // header) to evaluate Synchronize's own expression on Bullet's own values AFTER the unmodified React() has run.
 // React(), Synchronize(), Fix() and the whole of Bullet run as the reference compiled them.
+// Include order as in oracle/ref_harness.cpp and for the same reason: Matrix4f::Inverse (L/util/math_impl.inl:844-861, called by
+// PoserMotionState::Fix) and Bezier::interpolate call an UNQUALIFIED `abs`; the viewer's translation unit has seen <math.h> /
+// <stdlib.h> (through sokol and imgui, main.cpp:10-20) before mmd.hxx (main.cpp:22), so ::abs(float) is what binds.  With
+// mmd.hxx first g++ binds ::abs(int), every row scale of a rotation truncates to 0 and Inverse() returns the zero matrix --
+// the first build of this harness did exactly that and every strict body's bone collapsed.  The oracle follows the application.
+#include <math.h>
+#include <stdlib.h>
+
 #include <cstdint>
 #include <cstring>
 #include <string>

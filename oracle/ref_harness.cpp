@@ -29,6 +29,10 @@
 
 #include <mmd/mmd.hxx>
 
+// the reference-side binding a maintainer would add to the viewer, compiled here against the real
+// libmmd so that the GPU box can run it end to end; only its libmmd-facing half is used (nothing of libmmdx is linked)
+#include "../simple_mmd_renderer_amd/host/libmmd_glue.hpp"
+
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -58,9 +62,11 @@ public:
     // What BulletPhysicsReactor::React does to a poser once the world has been stepped
     // (mmd-bullet_impl.inl:312-326): PoserMotionState::Synchronize of every body physics moved (:34-40, the body's
     // transform becomes the bone's skinning matrix), then PoserMotionState::Fix of every strict one (:42-56).
-    // Bullet is not built here (the reactor needs the whole library); the bodies' transforms are the caller's
-    // input and the two small member functions are re-expressed with libmmd's OWN matrix operators
-    // (operator*, Inverse, the vector add) on libmmd's OWN BoneImage -- the arithmetic under test is the library's.
+    // Here the bodies' transforms are the CALLER's input (random, also non-rigid ones Bullet never produces) and the
+    // two small member functions are re-expressed with libmmd's OWN matrix operators (operator*, Inverse, the vector
+    // add) on libmmd's OWN BoneImage.  The REAL reactor -- mmd::BulletPhysicsReactor over the vendored Bullet, which
+    // does build here with plain g++ -- runs in oracle/ref_bullet_harness.cpp and pins the same seam with its own
+    // Synchronize / Fix / React (tests/test_bullet_reactor.py, tests/golden/rig_bullet_expect.npz).
     static void Synchronize(mmd::Poser &poser, size_t bone, const float *skinning) {
         std::memcpy(GetPoserBoneImage(poser, bone).skinning_matrix_.v, skinning, 64);
     }
@@ -405,6 +411,20 @@ double mmdref_time_motion_solve(void *motion, void *ref, uint32_t instances, con
 }
 
 void mmdref_destroy(void *h) { delete static_cast<Ref *>(h); }
+
+// host/libmmd_glue.hpp: mmd::Model -> the flat arrays + descriptor mmdx_model_create takes (the caller creates the model
+// and frees the arrays afterwards), and the palette through the glue's PhysicsReactor-derived tap.
+void *mmdref_glue_flatten(void *h, mmdx_model_desc *desc, uint32_t flags) {
+    mmdx::glue::FlatModel *f = new mmdx::glue::FlatModel;
+    mmdx::glue::Flatten(static_cast<Ref *>(h)->model, *f);
+    *desc = f->Desc(flags);
+    return f;
+}
+void mmdref_glue_free(void *flat) { delete static_cast<mmdx::glue::FlatModel *>(flat); }
+void mmdref_glue_read_palette(void *h, float *out) {
+    Ref *r = static_cast<Ref *>(h);
+    mmdx::glue::PaletteTap::Read(*r->poser, r->model.GetBoneNum(), out);
+}
 
 // Skin tags after the optional Normalize() -- lets tests check the load-time retagging.
 void mmdref_get_skin(void *h, int32_t *type_out, int64_t *ids_out, float *w_out) {
