@@ -257,7 +257,7 @@ using ChainState = StateT<__attribute__((address_space(3))) float *, true>;  // 
 
 // float(sqrt(double(x))) is the correctly rounded f32 square root (rounding twice is innocuous for sqrt when the
 // wide format has >= 2 x 24 + 2 bits), which is what sqrtf compiles to; sincos shares its argument reduction and
-// polynomials with sin and cos.  Both substitutions checked over all 2^32 floats: tools/libm_probe.hip.
+// polynomials with sin and cos.  Both substitutions checked over all 2^32 floats: tools/probes/libm_probe.hip.
 __device__ __forceinline__ float d_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ void d_sincos(float x, float *s, float *c) {
     double ds, dc;

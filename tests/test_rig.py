@@ -6,7 +6,7 @@ mmdx_vmd_bind_bones / mmdx_skeleton_create.  GPU tests compare the HIP kernels w
 fixture through the C ABI: bit-exact, no tolerance, on every seed used here.  (Stated tolerance of the IK solve
 beyond these seeds: its sin/cos/asin/acos/atan2 go through the device's double libm where the reference's go
 through glibc's; soaks of 4.6 million random solves found one instance whose palette differs, by 3.8e-6 at most --
-DESIGN.md section 7 row 3, tools/soak_rig.py, tools/rig_mismatch_probe.py.)
+DESIGN.md section 7 row 3, tools/soak_rig.py, tools/probes/rig_mismatch_probe.py.)
 """
 import os
 

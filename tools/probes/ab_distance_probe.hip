@@ -1,5 +1,5 @@
-// tools/ab_distance_probe.hip -- the deform store pattern's rate as a function of the DISTANCE between the two output
-// arrays (positions a, normals b) inside one large allocation.  tools/alloc_api_probe showed: adjacent arrays are slow,
+// tools/probes/ab_distance_probe.hip -- the deform store pattern's rate as a function of the DISTANCE between the two output
+// arrays (positions a, normals b) inside one large allocation.  tools/probes/alloc_api_probe showed: adjacent arrays are slow,
 // arrays 9 GB apart are fast.  Which distances are fast?  Measurement tool only.
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,4 +1,4 @@
-// tools/alloc_api_probe.hip -- does the allocation API decide the store-pattern mode?  For each way of obtaining the
+// tools/probes/alloc_api_probe.hip -- does the allocation API decide the store-pattern mode?  For each way of obtaining the
 // crowd's two output arrays (614 MB each): allocate, time a linear fill and the deform store pattern, free; repeated.
 // Also: sub-ranges of ONE large allocation.  Measurement tool only (hipcc --offload-arch=gfx950 -O2).
 #include <hip/hip_runtime.h>

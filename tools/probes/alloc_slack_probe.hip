@@ -1,5 +1,5 @@
-// tools/alloc_slack_probe.hip -- why does tools/store_pattern_probe see the fast store mode on every allocation while
-// tools/alloc_api_probe sees it on one in seven?  Candidates: the 4 MiB of slack the former allocates, its 97 (not 98)
+// tools/probes/alloc_slack_probe.hip -- why does tools/probes/store_pattern_probe see the fast store mode on every allocation while
+// tools/probes/alloc_api_probe sees it on one in seven?  Candidates: the 4 MiB of slack the former allocates, its 97 (not 98)
 // tiles per instance, its 2-D grid.  Measurement tool only.
 #include <hip/hip_runtime.h>
 #include <cstdio>

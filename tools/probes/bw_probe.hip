@@ -1,4 +1,4 @@
-// tools/bw_probe.hip -- store/copy bandwidth probe for gfx950: which write shape reaches the HBM
+// tools/probes/bw_probe.hip -- store/copy bandwidth probe for gfx950: which write shape reaches the HBM
 // ceiling?  Measurement tool only (not part of the product).  Build: hipcc --offload-arch=gfx950 -O3
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Per-phase kernel durations and launch gaps of tools/event_overhead_probe.py from its rocprofv3 kernel trace:
-    rocprofv3 --kernel-trace --output-format csv -d OUT -o evt -- python3 tools/event_overhead_probe.py
-    python tools/event_overhead_analyze.py OUT/evt_kernel_trace.csv"""
+"""Per-phase kernel durations and launch gaps of tools/probes/event_overhead_probe.py from its rocprofv3 kernel trace:
+    rocprofv3 --kernel-trace --output-format csv -d OUT -o evt -- python3 tools/probes/event_overhead_probe.py
+    python tools/probes/event_overhead_analyze.py OUT/evt_kernel_trace.csv"""
 import csv
 import sys
 

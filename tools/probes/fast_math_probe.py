@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """MMDX_CREATE_FAST_MATH: how far the contracted kernels' results are from the oracle's (bit-exact default next to them), and what
-the contraction buys: config-3 crowd step, per-instance-morph workloads, single frames.  python tools/fast_math_probe.py"""
+the contraction buys: config-3 crowd step, per-instance-morph workloads, single frames.  python tools/probes/fast_math_probe.py"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from oracle.pyoracle import Oracle  # noqa: E402

@@ -2,7 +2,7 @@
 """When does the long CCD chain of the bench rig start to repeat itself?  Builds the C oracle with -DMMDX_IK_CYCLE_STATS (a diagnostic
 that hashes the links' IK rotations after every sweep) into /tmp, solves the rig for N instances at the bench's poses on the CPU and
 prints, per half of the iterations, the distribution of the first sweep that reproduced the state of 1, 2, 3 or 4 sweeps earlier.
-The poses come from the device's keyframe evaluation (the bench's motion), the solve runs on the CPU.   python tools/ik_cycle_probe.py [instances]"""
+The poses come from the device's keyframe evaluation (the bench's motion), the solve runs on the CPU.   python tools/probes/ik_cycle_probe.py [instances]"""
 import ctypes as C
 import os
 import subprocess
@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 so = "/tmp/libmmdx_oracle_cycle.so"
 subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-DMMDX_IK_CYCLE_STATS",

@@ -2,7 +2,7 @@
 //   float(sqrt(double(x)))  ==  sqrtf(x)          (correctly rounded f32 sqrt; double rounding is innocuous
 //                                                   for sqrt when the wide format has >= 2p+2 bits)
 //   sin(double(x)), cos(double(x))  ==  the two results of sincos(double(x))
-// Build and run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/libm_probe.hip -o tools/libm_probe && tools/libm_probe
+// Build and run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/libm_probe.hip -o tools/probes/libm_probe && tools/probes/libm_probe
 // With a file argument: replay mode, see replay() below.
 #include <hip/hip_runtime.h>
 
@@ -29,7 +29,7 @@ __global__ void probe(unsigned long long *bad) {
     if (b_cos) atomicAdd(bad + 2, b_cos);
 }
 
-// Replay mode (tools/rig_mismatch_probe.py): records of the oracle's transcendental calls -- function id (0 sqrt,
+// Replay mode (tools/probes/rig_mismatch_probe.py): records of the oracle's transcendental calls -- function id (0 sqrt,
 // 1 sin, 2 cos, 3 asin, 4 acos, 5 atan2), argument bits, second argument bits, result bits -- evaluated the way
 // the bone solver does on the device; prints every call whose float result differs from the host's.
 __global__ void replay(const uint32_t *rec, size_t n, uint32_t *out_f, double *out_d) {

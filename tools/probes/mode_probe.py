@@ -6,7 +6,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import _capi as api  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeviceBuffer  # noqa: E402

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """One allocation holding both crowd output arrays: how does the store-pattern rate depend on the byte
-offset between array a and array b?  (tools/alloc_probe.py showed the rate is bimodal across separate
+offset between array a and array b?  (tools/probes/alloc_probe.py showed the rate is bimodal across separate
 allocations, i.e. it depends on the physical placement of the two arrays relative to each other.)"""
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import _capi as api  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeviceBuffer  # noqa: E402

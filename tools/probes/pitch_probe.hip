@@ -1,5 +1,5 @@
 // Store-only replay of the crowd output pattern with a configurable per-instance pitch: does some pitch make the
-// slow placement mode go away?   hipcc --offload-arch=gfx950 -O3 tools/pitch_probe.hip -o tools/pitch_probe
+// slow placement mode go away?   hipcc --offload-arch=gfx950 -O3 tools/probes/pitch_probe.hip -o tools/probes/pitch_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,10 +1,10 @@
-// tools/placement_ab_probe.hip -- is the slow store mode an interference between the TWO output arrays?  Per pair of fresh allocations:
+// tools/probes/placement_ab_probe.hip -- is the slow store mode an interference between the TWO output arrays?  Per pair of fresh allocations:
 //   P1  the crowd pattern: every workgroup writes its 6 KiB piece of a, then of b, per instance (the deform kernel's rhythm)
 //   P2  the same bytes per workgroup and step, but a workgroup writes ONE array only: pieces of two instances per step; the first half
 //       of the grid writes a, the second half b (a and b are then mostly written at different times)
 //   P3  lock-step like P1, but the b piece belongs to the instance S rows further on (same bytes, the a / b pairing shifted by S x 600 KB)
 //   P4  like P1 with 768-byte alternation inside the piece (the tile-order kernel's rhythm: wave w writes its 768 B of a, then of b)
-// Measurement tool only.   hipcc --offload-arch=gfx950 -O2 tools/placement_ab_probe.hip -o tools/placement_ab_probe
+// Measurement tool only.   hipcc --offload-arch=gfx950 -O2 tools/probes/placement_ab_probe.hip -o tools/probes/placement_ab_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

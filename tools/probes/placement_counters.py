@@ -2,7 +2,7 @@
 """The slow / fast store mode of the crowd's output arrays (a property of the physical backing hipMalloc
 hands out) under the hardware counters: which unit is waiting in the slow mode?
 
-    python tools/probes/placement_counters.py fast|slow       (under rocprofv3 --pmc ...: tools/r03_run3.sh)
+    python tools/probes/placement_counters.py fast|slow       (under rocprofv3 --pmc ...: tools/probes/r03_run3.sh)
 
 Allocates up to PC_TRIES candidate pairs of output arrays WITHOUT freeing any (every try draws fresh physical memory), times
 the store-only replay of the crowd pattern on each, keeps the fastest (`fast`) or the slowest (`slow`) pair, frees the rest,

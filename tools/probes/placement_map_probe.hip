@@ -1,8 +1,8 @@
-// tools/placement_map_probe.hip -- what distinguishes the placements of the crowd's two output arrays that store at the
-// linear-fill rate from the ones that store ~25 % slower (tools/alloc_api_probe.hip, profiles/r02/placement_probes.txt)?
+// tools/probes/placement_map_probe.hip -- what distinguishes the placements of the crowd's two output arrays that store at the
+// linear-fill rate from the ones that store ~25 % slower (tools/probes/alloc_api_probe.hip, profiles/r02/placement_probes.txt)?
 // Per pair of fresh allocations: each array alone, the pair, the pair with the tile -> XCD assignment rotated, the pair
 // quantised to whole 4 KiB blocks, two lock-step linear fills, and the pair restricted to eighths of the instance range.
-// Measurement tool only.   hipcc --offload-arch=gfx950 -O2 tools/placement_map_probe.hip -o tools/placement_map_probe
+// Measurement tool only.   hipcc --offload-arch=gfx950 -O2 tools/probes/placement_map_probe.hip -o tools/probes/placement_map_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

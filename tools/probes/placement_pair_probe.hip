@@ -1,7 +1,7 @@
-// tools/placement_pair_probe.hip -- structure of the fast / slow placements of the crowd's two output arrays: is "fast" a property of
+// tools/probes/placement_pair_probe.hip -- structure of the fast / slow placements of the crowd's two output arrays: is "fast" a property of
 // each array or of the PAIR?  (1) 8 separately allocated arrays, the store pattern and a lock-step linear fill for all 28
 // pairs;  (2) one large allocation, array b at a + D for a ladder of distances D (sub-page to hundreds of MiB).
-// Measurement tool only.   hipcc --offload-arch=gfx950 -O2 tools/placement_pair_probe.hip -o tools/placement_pair_probe
+// Measurement tool only.   hipcc --offload-arch=gfx950 -O2 tools/probes/placement_pair_probe.hip -o tools/probes/placement_pair_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

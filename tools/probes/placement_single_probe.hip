@@ -1,8 +1,8 @@
-// tools/placement_single_probe.hip -- is the fast / slow store mode a property of each ARRAY (then a pair is fast iff both are good,
+// tools/probes/placement_single_probe.hip -- is the fast / slow store mode a property of each ARRAY (then a pair is fast iff both are good,
 // and arrays can be shopped for one by one) or of the pair?  N separately allocated arrays: the crowd pattern written into ONE array
 // (every workgroup writes the pieces of two instances per step, so the bytes per workgroup and step are those of the pair pattern),
 // then the pair pattern for all pairs.  Measurement tool only.
-//   hipcc --offload-arch=gfx950 -O2 tools/placement_single_probe.hip -o tools/placement_single_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/placement_single_probe.hip -o tools/probes/placement_single_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

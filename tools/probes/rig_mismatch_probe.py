@@ -2,17 +2,17 @@
 """Diagnose a soak mismatch of the device bone solve: for the given rig seeds (tools/soak_rig.py numbering) find
 the instances that differ from the C oracle, re-solve them a few times (a race would not repeat), and solve the
 same inputs with the schedule switched off (MMDX_SOLVE_SEQUENTIAL=1, one event per round) in a child process:
-equal results there mean the difference is arithmetic, not ordering.  With tools/libm_probe built (see
-tools/libm_probe.hip) every transcendental call the oracle made for the instance is replayed on the device to show
+equal results there mean the difference is arithmetic, not ordering.  With tools/probes/libm_probe built (see
+tools/probes/libm_probe.hip) every transcendental call the oracle made for the instance is replayed on the device to show
 which call the two libms disagree on.
-    python tools/rig_mismatch_probe.py first_seed last_seed [instances]"""
+    python tools/probes/rig_mismatch_probe.py first_seed last_seed [instances]"""
 import os
 import subprocess
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import synth, vmd  # noqa: E402
 

@@ -4,7 +4,7 @@
 (The labels say "serial": the solver's ABI name, MMDX_SOLVER_SERIAL.)"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from simple_mmd_renderer_amd import _capi as api, synth, vmd

@@ -3,7 +3,7 @@
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MMDX_PLACEMENT_LOG", "1")
 from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402

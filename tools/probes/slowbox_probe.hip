@@ -1,4 +1,4 @@
-// tools/slowbox_probe.hip -- which property of the crowd store pattern costs bandwidth on the "slow"
+// tools/probes/slowbox_probe.hip -- which property of the crowd store pattern costs bandwidth on the "slow"
 // boxes (two arrays? persistent blocks? distance between concurrently written regions?)
 #include <hip/hip_runtime.h>
 #include <cstdio>

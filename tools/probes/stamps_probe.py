@@ -3,7 +3,7 @@
 split of the deform kernel for the shared-morph crowd and the per-instance-morph crowd."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["MMDX_DEBUG_STAMPS"] = "1"
 from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402

@@ -1,4 +1,4 @@
-// tools/store_align_probe.hip -- does the deform store pattern's bandwidth depend on the relative
+// tools/probes/store_align_probe.hip -- does the deform store pattern's bandwidth depend on the relative
 // placement of the two output arrays / the instance stride?  Measurement tool only.
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,4 +1,4 @@
-// tools/store_map_probe.hip -- how should a 256-thread workgroup map its 768 16-byte stores (6 KB of
+// tools/probes/store_map_probe.hip -- how should a 256-thread workgroup map its 768 16-byte stores (6 KB of
 // array A + 6 KB of array B per instance) onto lanes?  M0: store i covers chunks [256i, 256i+256)
 // (each wave-store 1 KB, a wave's three stores 4 KB apart).  M1: wave w owns 3 consecutive KB.
 // M2: thread owns 3 consecutive chunks (48 B).  Crowd pattern (tile, 16 strided instances), for

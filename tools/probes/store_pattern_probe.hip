@@ -1,4 +1,4 @@
-// tools/store_pattern_probe.hip -- which (tile size, grid order, stagger) makes the deform store
+// tools/probes/store_pattern_probe.hip -- which (tile size, grid order, stagger) makes the deform store
 // pattern reach the linear-fill rate on every box?  Measurement tool only.
 #include <hip/hip_runtime.h>
 #include <cstdio>

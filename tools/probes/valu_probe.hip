@@ -1,7 +1,7 @@
 // valu_probe.hip -- issue cost of packed vs scalar f32 VALU instructions on gfx950, one workgroup on one CU.
 // Each wave runs a loop of 16 INDEPENDENT instructions of one kind (8 accumulator registers / register pairs, two
 // rounds); reported: s_memtime ticks per instruction for 1, 2 and 4 waves per SIMD, relative to v_mul_f32.
-//   hipcc --offload-arch=gfx950 -O2 tools/valu_probe.hip -o tools/valu_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/valu_probe.hip -o tools/probes/valu_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

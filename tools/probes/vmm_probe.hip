@@ -1,6 +1,6 @@
 // How does the backing of the two crowd output arrays (614.4 MB each) affect the store-only replay of
 // the deform kernel's output pattern?  hipMalloc vs the virtual-memory API with physical chunks of a
-// chosen size mapped into one contiguous range.   hipcc --offload-arch=gfx950 -O3 tools/vmm_probe.hip -o tools/vmm_probe
+// chosen size mapped into one contiguous range.   hipcc --offload-arch=gfx950 -O3 tools/probes/vmm_probe.hip -o tools/probes/vmm_probe
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
