@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""The slow / fast store mode of the crowd's output arrays (a property of the physical backing hipMalloc
-hands out) under the hardware counters: which unit is waiting in the slow mode?
+"""The slow / fast store mode of the crowd's output arrays (LAB_NOTES.md: a property of the physical backing hipMalloc hands
+out) under the hardware counters: which unit is waiting in the slow mode?
 
-    python tools/probes/placement_counters.py fast|slow       (under rocprofv3 --pmc ...: tools/probes/r03_run3.sh)
+    rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d DIR -o p -- python3 tools/probes/placement_counters.py
+    python3 tools/probes/placement_counters.py --analyze DIR [DIR ...]
 
-Allocates up to PC_TRIES candidate pairs of output arrays WITHOUT freeing any (every try draws fresh physical memory), times
-the store-only replay of the crowd pattern on each, keeps the fastest (`fast`) or the slowest (`slow`) pair, frees the rest,
-then runs 12 pattern replays, 12 linear fills and 24 crowd kernels (config 3, morph pass skipped) on the chosen pair.
-Prints the pair's pattern rate so the counters can be read against it."""
-import ctypes as C
+ONE process allocates PC_PAIRS pairs of output arrays and keeps them all (every pair is fresh physical memory); on every
+pair, in turn: 3 store-only replays of the crowd pattern, then 3 crowd kernels (config 3, morph pass skipped).  Nothing is
+selected by a rate measured under the profiler: the analysis reads every dispatch's own duration from the kernel trace and puts
+the counters of the same dispatch next to it, pair by pair -- fast and slow placements side by side from one run."""
+import collections
+import csv
 import os
 import sys
 
@@ -16,52 +18,55 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
-from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
+
+REPS = 3
+
+
+def analyze(dirs):
+    for d in dirs:
+        kt = sorted(csv.DictReader(open(os.path.join(d, "p_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
+        cc = list(csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))))
+        ctr = collections.defaultdict(dict)
+        for r in cc:
+            ctr[r["Dispatch_Id"]][r["Counter_Name"]] = ctr[r["Dispatch_Id"]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        names = sorted({r["Counter_Name"] for r in cc})
+        for kind in ("pattern_fill_kernel", "deform_kernel"):
+            rows = [r for r in kt if kind in r["Kernel_Name"]]
+            if kind == "deform_kernel":
+                rows = rows[1:]                               # the first launch ran the morph pass's set-up call
+            groups = [rows[i:i + REPS] for i in range(0, len(rows) - len(rows) % REPS, REPS)]
+            print(f"== {d}: {kind}, per pair (mean of {REPS} launches): duration us | " + " | ".join(names))
+            for g in sorted(groups, key=lambda g: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in g)):
+                us = np.mean([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in g])
+                vals = [np.mean([ctr[r["Dispatch_Id"]].get(n, 0.0) for r in g]) for n in names]
+                print(f"   {us:8.1f} | " + " | ".join(f"{v:14.0f}" for v in vals))
 
 
 def main():
-    mode = sys.argv[1] if len(sys.argv) > 1 else "fast"
+    if len(sys.argv) > 2 and sys.argv[1] == "--analyze":
+        return analyze(sys.argv[2:])
+    from simple_mmd_renderer_amd import _capi as api, synth
+    from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer
+    import ctypes as C
     m = synth.make_config("config3_crowd")
     ni = 1024
     dm = DeformModel(m)
     sa, sb = dm.out_sizes(api.OUT_SOA, ni)
     lib = api.lib()
-
-    def rate(a, b, iters=5):
-        ms = C.c_float(0)
-        api.check(lib.mmdx_bench_store_pattern(a.ptr, b.ptr, m.nv, ni, iters, C.byref(ms)))
-        return (sa + sb) / (ms.value * 1e-3) / 1e9
-    cands = []
-    for _ in range(int(os.environ.get("PC_TRIES", "24"))):
-        a, b = DeviceBuffer(sa), DeviceBuffer(sb)
-        cands.append((rate(a, b), a, b))
-        if mode == "fast" and cands[-1][0] > 6400:
-            break
-        if mode == "slow" and cands[-1][0] < 5300:
-            break
-    cands.sort(key=lambda c: c[0])
-    chosen = cands[-1] if mode == "fast" else cands[0]
-    print("candidate pattern rates GB/s:", " ".join(f"{c[0]:.0f}" for c in cands), flush=True)
-    for c in cands:
-        if c is not chosen:
-            c[1].free(); c[2].free()
-    _, d_a, d_b = chosen
-    for _ in range(30):                                   # the driver wipes the freed candidates in the background: wait it out
-        rate(d_a, d_b, 5)
-    print(f"mode {mode}: chosen pair stores the crowd pattern at {rate(d_a, d_b, 10):.0f} GB/s", flush=True)
-    ms = C.c_float(0)
-    api.check(lib.mmdx_bench_fill(d_a.ptr, sa, 12, C.byref(ms)))
-    print(f"linear fill of array a: {sa / (ms.value * 1e-3) / 1e9:.0f} GB/s", flush=True)
     pals = synth.make_palettes(m, (np.arange(ni) * 3) % 1801)
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(synth.morph_weights(m.nm, 30)[0])
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
-    dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+    pairs = [(DeviceBuffer(sa), DeviceBuffer(sb)) for _ in range(int(os.environ.get("PC_PAIRS", "10")))]
+    dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, pairs[0][0].ptr, pairs[0][1].ptr, api.OUT_SOA, flags)     # the morph pass, once
     dm.sync()
-    dm.timer_start()
-    for _ in range(24):
-        dm.deform_batched_raw(ni, None, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags | api.MORPH_UNCHANGED)
-    print(f"crowd kernel alone: {dm.timer_stop() / 24 * 1e3:.1f} us", flush=True)
+    ms = C.c_float(0)
+    for a, b in pairs:
+        api.check(lib.mmdx_bench_store_pattern(a.ptr, b.ptr, m.nv, ni, REPS - 1, C.byref(ms)))     # 1 warm-up + REPS-1 timed = REPS launches
+    for a, b in pairs:
+        for _ in range(REPS):
+            dm.deform_batched_raw(ni, None, d_pal.ptr, a.ptr, b.ptr, api.OUT_SOA, flags | api.MORPH_UNCHANGED)
+        dm.sync()
+    print("done", flush=True)
 
 
 if __name__ == "__main__":
