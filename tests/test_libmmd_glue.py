@@ -50,6 +50,47 @@ def test_glue_header_compiles_against_libmmd_and_agrees_with_the_loader(hip_lib,
     assert r.returncode == 0 and "GLUE OK" in r.stdout, r.stdout + r.stderr
 
 
+def _glue_model(ref, hip_lib, flags):
+    """mmd::Model of `ref` -> glue::Flatten (inside libmmd_ref.so) -> mmdx_model_create; returns (handle, desc)."""
+    ref.lib.mmdref_glue_flatten.restype = C.c_void_p
+    ref.lib.mmdref_glue_flatten.argtypes = [C.c_void_p, C.POINTER(api.ModelDesc), C.c_uint32]
+    ref.lib.mmdref_glue_free.argtypes = [C.c_void_p]
+    ref.lib.mmdref_glue_read_palette.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    desc = api.ModelDesc()
+    flat = ref.lib.mmdref_glue_flatten(ref.h, C.byref(desc), flags)
+    assert flat
+    h = C.c_void_p()
+    try:
+        api.check(hip_lib.mmdx_model_create(C.byref(desc), C.byref(h)))
+    finally:
+        ref.lib.mmdref_glue_free(flat)
+    return h, desc
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
+def test_glue_through_the_reference_harness_host_only(hip_lib):
+    """The call sequence of the GPU test below, without a GPU: the flattened model validates and compiles (host-only) to the same
+    skin tags as the bundled loader's, and the tap reads back an injected palette."""
+    from simple_mmd_renderer_amd import pmx
+    from simple_mmd_renderer_amd.engine import DeformModel
+    ref = Reference.from_pmx(PMX)
+    h, desc = _glue_model(ref, hip_lib, api.CREATE_HOST_ONLY)         # PmxReader already ran Normalize: no MMDX_CREATE_NORMALIZE
+    nv, nb = desc.n_vertices, desc.n_bones
+    t, ids, w = np.empty(nv, np.int32), np.empty((nv, 4), np.int32), np.empty((nv, 4), np.float32)
+    api.check(hip_lib.mmdx_model_get_skin(h, t.ctypes.data_as(C.POINTER(C.c_int32)), ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          w.ctypes.data_as(C.POINTER(C.c_float))))
+    hip_lib.mmdx_model_destroy(h)
+    with DeformModel(pmx.load_pmx(PMX).flat, normalize=True, host_only=True) as dm:
+        t2, ids2, w2 = dm.get_skin()
+    assert np.array_equal(t, t2) and np.array_equal(ids, ids2) and np.array_equal(w.view(np.uint32), w2.view(np.uint32))
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "pmx_small_expect.npz"))
+    ref.set_palette(z["palette"][1])
+    pal = np.zeros((nb, 16), np.float32)
+    ref.lib.mmdref_glue_read_palette(ref.h, pal.ctypes.data_as(C.POINTER(C.c_float)))
+    gu.assert_bits_equal(pal, z["palette"][1].reshape(nb, 16), "the tap reads what the reactor-side door wrote")
+    ref.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not reference_available(), reason="oracle/_ref/libmmd_ref.so not built")
 def test_gpu_glue_to_deform_vertex32_vs_libmmd_golden(hip_lib):
@@ -59,12 +100,7 @@ def test_gpu_glue_to_deform_vertex32_vs_libmmd_golden(hip_lib):
     assert device_count() >= 1
     z = np.load(os.path.join(gu.GOLDEN_DIR, "pmx_small_expect.npz"))
     ref = Reference.from_pmx(PMX)
-    desc = api.ModelDesc()
-    flat = C.c_void_p(ref.lib.mmdref_glue_flatten(ref.h, C.byref(desc), C.c_uint32(0)))   # PmxReader already ran Normalize
-    assert flat.value
-    h = C.c_void_p()
-    api.check(hip_lib.mmdx_model_create(C.byref(desc), C.byref(h)))
-    ref.lib.mmdref_glue_free(flat)
+    h, desc = _glue_model(ref, hip_lib, 0)
     nv, nb = desc.n_vertices, desc.n_bones
     for f in range(z["rates"].shape[0]):
         ref.set_palette(z["palette"][f])
