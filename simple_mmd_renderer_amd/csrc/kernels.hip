@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(kThreads) void pattern_fill_kernel(float4 *a, float
     for (uint32_t g = grp * 16; g < min(ni, grp * 16 + 16); ++g) {
         const size_t base_a = (size_t(g) * nv + v0) * bpva / 16, base_b = (size_t(g) * nv + v0) * bpvb / 16;
         for (uint32_t q = threadIdx.x; q < pa + pb; q += kThreads) {
-            if (q < pa) a[base_a + q] = v; else b[base_b + q - pa] = v;
+            store16(q < pa ? a + base_a + q : b + base_b + (q - pa), v);      // the deform kernel's store instruction (policy and all)
         }
     }
 }

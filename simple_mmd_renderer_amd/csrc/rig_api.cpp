@@ -224,6 +224,8 @@ mmdx_status mmdx_skeleton_create(const mmdx_skeleton_desc *desc, mmdx_skeleton_t
     if (!desc || !out || desc->struct_size != sizeof(mmdx_skeleton_desc))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or mmdx_skeleton_desc.struct_size mismatch");
     *out = nullptr;
+    if (desc->create_flags & ~uint32_t(MMDX_SKELETON_PHYSICS_SEAM))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown bits in mmdx_skeleton_desc.create_flags");
     try {
         std::unique_ptr<mmdx_skeleton_s> s(new mmdx_skeleton_s);
         std::string err;

@@ -153,6 +153,7 @@ public:
         check(mmdx_skeleton_solve_pre(skeleton_, model_, 1, bone_poses_.data(), nm_ ? morph_rates_.data() : nullptr,
                                       MMDX_WEIGHTS_SHARED, palette_.data()));
         physics_bones_.clear(); physics_strict_.clear(); physics_skinning_.clear();
+        post_pending_ = true;       // the rows of the post-physics bones are unspecified until PostPhysicsPosing()
     }
     void SetPhysicsTransforms(const std::vector<int32_t> &bones, const std::vector<uint8_t> &strict,
                               const float *skinning /*[bones.size()][16]*/) {
@@ -168,6 +169,7 @@ public:
         ov.n_bones = uint32_t(physics_bones_.size());
         ov.bone = physics_bones_.data(); ov.strict = physics_strict_.data(); ov.skinning = physics_skinning_.data();
         check(mmdx_skeleton_solve_post(skeleton_, model_, 1, ov.n_bones ? &ov : nullptr, 0, palette_.data()));
+        post_pending_ = false;
     }
 
     // original_to_engine[file vertex] = its position in pose_image of an MMDX_CREATE_TILE_ORDER poser (what the viewer's index
@@ -186,12 +188,16 @@ public:
 
     // What a PhysicsReactor-derived tap reads out of the reference Poser after PostPhysicsPosing():
     // float[16], row-vector convention, translation in elements 12..14.
+    // (Between PrePhysicsPosing() and PostPhysicsPosing() only the pre-physics bones' matrices are valid -- what a reactor's
+    // kinematic bodies read; the frame's palette is final after PostPhysicsPosing(), as in the reference, main.cpp:1810.)
     float *SkinningMatrix(size_t bone) { return palette_.data() + bone * 16; }
     void SetSkinningMatrices(const float *palette /*[NB][16]*/) {
         std::memcpy(palette_.data(), palette, palette_.size() * sizeof(float));
+        post_pending_ = false;      // the caller supplied the whole palette
     }
 
     void Deform() {
+        require_final_palette();
         check(mmdx_deform(model_, morph_rates_.data(), palette_.data(),
                           reinterpret_cast<float *>(pose_image.coordinates.data()),
                           reinterpret_cast<float *>(pose_image.normals.data())));
@@ -203,6 +209,7 @@ public:
     template <class Alloc>
     void UpdateDeformedVertices(std::vector<Vertex, Alloc> &vertices, float mmd_to_meter = 0.1f) {
         vertices.resize(nv_);
+        require_final_palette();
         check(mmdx_deform_vertex32(model_, morph_rates_.data(), palette_.data(), mmd_to_meter,
                                    vertices.data()));
     }
@@ -213,6 +220,16 @@ public:
     uint32_t morph_count() const { return nm_; }
 
 private:
+    // Until round 2 PrePhysicsPosing() solved both bone lists; since the physics seam it solves the pre-physics list only.  A
+    // host that still calls PrePhysicsPosing() and then deforms would skin with unspecified rows for the post-physics bones:
+    // refuse loudly instead.
+    void require_final_palette() const {
+        if (post_pending_)
+            throw Error(MMDX_ERR_INVALID_ARGUMENT, "Deform() after PrePhysicsPosing() without PostPhysicsPosing(): the post-physics "
+                                                   "bones' skinning matrices are not solved yet (main.cpp:1801-1810 calls both)");
+    }
+    bool post_pending_ = false;
+
     explicit Poser(mmdx_pmx_t pmx) {
         mmdx_model_desc d;
         check(mmdx_pmx_get_model_desc(pmx, &d));
