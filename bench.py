@@ -427,6 +427,41 @@ def pmc_traffic(is_default_layout: bool, ni: int, nv: int):
         "write_bytes": write, "fetch_bytes_reported": fetch, "fetch_correction": 2.0, "source": src}}
 
 
+def fused_pmc_traffic(out):
+    """Counter-side HBM traffic of the per-instance-morph workloads ("reported per kernel from rocprofv3 AND from the
+    algorithmic figure; both go in the JSON"): WRITE_SIZE + 2 x FETCH_SIZE per launch from the committed separate PMC passes
+    (profiles/rNN/fused_gather_pmc.csv, tools/profile_round.sh stage 7; gfx950 FETCH correction as in pmc_traffic), divided by THIS
+    run's time per launch.  The launch is identified by its grid size; withheld when the recorded build is not the running one."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "fused_gather_pmc.csv")))
+    if not files:
+        return
+    meta_path = files[-1][:-4] + ".meta.json"
+    src = os.path.relpath(files[-1], ROOT)
+    if not os.path.exists(meta_path) or json.load(open(meta_path)).get("kernel_source_sha") != kernel_source_sha():
+        for k in ("config2_64_frames_per_launch", "config3prime_per_instance_morphs", "config5_64_frames_per_launch_fp16"):
+            if k in out and "error" not in out[k]:
+                out[k]["pmc_traffic_withheld"] = f"{src} was collected for another build"
+        return
+    grids = {"config2_64_frames_per_launch": "401408", "config3prime_per_instance_morphs": "3211264",
+             "config5_64_frames_per_launch_fp16": "1048576"}
+    rows = list(csv.DictReader(open(files[-1])))
+    for k, grid in grids.items():
+        if k not in out or "error" in out[k]:
+            continue
+        v = {r["counter"]: float(r["mean"]) * 1024 for r in rows if "deform_kernel" in r["kernel"] and r["grid_threads"] == grid
+             and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE")}
+        if len(v) != 2:
+            continue
+        traffic = v["WRITE_SIZE"] + 2 * v["FETCH_SIZE"]
+        ms = out[k]["ms_per_call"]
+        out[k].update({"pmc_traffic_bytes": traffic, "pmc_GBs": traffic / (ms * 1e-3) / 1e9,
+                       "pmc_frac_of_8TBs": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "pmc_traffic_over_algorithmic": traffic / (out[k]["algorithmic_GBs"] * 1e9 * ms * 1e-3),
+                       "pmc_source": src})
+
+
 def time_calls(dm, fn, iters, warm=3, settle_ms=60.0):
     """Average ms per call over `iters` back-to-back calls, after `warm` calls and -- like the headline
     measurement -- after the clock transient that follows an idle period: untimed batches until two
@@ -883,6 +918,7 @@ def extras(api, synth, DeformModel, DeviceBuffer, dm3, model3):
         b.free()
     dm5.close()
     cpu_reference_frame(out["config5_single_frame_fp16"], m5, rates, pals)
+    fused_pmc_traffic(out)
     return out
 
 

@@ -99,6 +99,11 @@ def extras(src, dst):
     counter_summary(src, ["pmc_sq1", "pmc_sq2"], os.path.join(dst, "config3_pmc_sq.csv"), ["deform_kernel", "morph_apply"])
     counter_summary(src, ["fused_fetch", "fused_write", "fused_sq1", "fused_sq2", "fused_tcc"],
                     os.path.join(dst, "fused_gather_pmc.csv"), ["deform_kernel", "flatten"])
+    # provenance for bench.py's counter-side figures of the per-instance-morph workloads (fused_pmc_traffic)
+    line = json.load(open(os.path.join(src, "bench_under_rocprof.json")))
+    with open(os.path.join(dst, "fused_gather_pmc.meta.json"), "w") as f:
+        json.dump({"kernel_source_sha": line["roofline"]["kernel_source_sha"],
+                   "collected_with": "tools/profile_round.sh stage 7 (tools/fused_bench.py c2 c5 c3p, separate --pmc passes)"}, f, indent=1)
     counter_summary(src, ["rig_sq1", "rig_sq2"], os.path.join(dst, "rig_pmc_sq.csv"), ["skeleton", "bone_track"])
     counter_summary(src, ["frame_sq1"], os.path.join(dst, "single_frame_pmc_sq.csv"), ["frame_kernel", "deform_kernel"])
     for a, b in (("fused_kt/kt_kernel_stats.csv", "fused_gather_kernel_stats.csv"), ("fused_plain.txt", "fused_gather_bench.txt"),
