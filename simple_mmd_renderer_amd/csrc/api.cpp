@@ -225,15 +225,13 @@ struct LaunchOverrides {
     int frame_kernel;   // MMDX_FRAME_KERNEL: 0 = a single frame always runs the tile kernel, 1 = models of fewer than 256 tiles run the
                         // frame kernel (default), 2 = always (A/B); MMDX_FRAME_THREADS: 128 / 256 lanes per workgroup
     int frame_threads;
-    int rotate;         // MMDX_ROTATE: A/B knob, every workgroup starts its instance group at a different instance
     int shared_fused;   // MMDX_SHARED_FUSED: crowds with a shared facial state gather the morphs inside the deform kernel: 0 never,
                         // 1 up to 8 instances (default), 2 always (A/B, tests)
 };
 LaunchOverrides read_launch_overrides() {
     return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
             env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
-            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_ROTATE", 0),
-            env_int("MMDX_SHARED_FUSED", 1)};
+            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1)};
 }
 LaunchOverrides &launch_overrides() {
     static LaunchOverrides o = read_launch_overrides();
@@ -565,7 +563,6 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     dp.finite_offsets = p.finite_offsets ? 1u : 0u;
     const LaunchOverrides &ov = launch_overrides();
     dp.interleave = uint32_t(ov.interleave);
-    dp.rotate = uint32_t(ov.rotate);
     dp.tile_order = (p.flags & MMDX_CREATE_TILE_ORDER) ? 1u : 0u;
 
     // ---- palettes -------------------------------------------------------------------------------
@@ -1070,10 +1067,9 @@ hipError_t time_store_pattern(void *a, void *b, uint32_t nv, uint32_t ni, uint32
     if (e != hipSuccess) return e;
     e = hipEventCreate(&e1);
     if (e != hipSuccess) { (void)hipEventDestroy(e0); return e; }
-    const uint32_t rot = uint32_t(launch_overrides().rotate);
-    e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr, rot);
+    e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr, rot);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.f;

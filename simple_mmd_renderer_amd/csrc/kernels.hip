@@ -258,9 +258,6 @@ struct RawEntry { using type = float4; };
 template <>
 struct RawEntry<true> { using type = uint2; };
 
-#ifndef MMDX_ROW_AHEAD_F16
-#define MMDX_ROW_AHEAD_F16 4u          // build-time A/B knob (tools/probes/store_policy_ab.py loads builds side by side)
-#endif
 constexpr uint32_t kRowAhead = 4;   // entries in flight per lane in the deform kernels; deeper (8) costs the fused kernels a wave per
                                     // SIMD and loses: measured.  The stand-alone morph pass has the registers for 16.
 
@@ -760,14 +757,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         float cz[VPT];
 #pragma unroll
         for (int k = 0; k < VPT; ++k) { cxy[k] = sl[k].pxy; cz[k] = sl[k].pz; }
-        // p.rotate (A/B knob, MMDX_ROTATE): every workgroup starts its group at a different instance, so that the workgroups
-        // running side by side write DIFFERENT instances at any one time (a wider footprint in the output arrays)
-        const uint32_t rot = (p.rotate && gcount) ? (tile * 5u + grp * 3u) % gcount : 0u;
-        for (uint32_t g = 0; g < gcount; ++g) {
-            uint32_t gg = g + rot;
-            gg -= gg >= gcount ? gcount : 0u;
-            run_instance(gg, cxy, cz);
-        }
+        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cxy, cz);
     } else if constexpr (MORPH == kMorphFused1) {
         // vertex_image = 0; for each applied entry: image = image + offset*rate
         // (poser_impl.inl:340-346); coordinate = base + image (:407)
@@ -801,8 +791,6 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         // instructions) measured 10 % slower: v_pk_mul_f32 / v_pk_add_f32 occupy the SIMD for two passes, so the
         // arithmetic time is the same and the position fix-up comes on top.
         float4 *wq = reinterpret_cast<float4 *>(smem + p.w_off);
-        // entries of a row in flight per lane: an f16 entry is two registers, an f32 one four -- twice as many fit the same budget
-        constexpr uint32_t kRowAhead4 = F16 ? MMDX_ROW_AHEAD_F16 : kRowAhead;
         // The first pack's weights were staged during the set-up.  When one float4 per thread covers a pack's weights,
         // the NEXT pack's are fetched into a register before this pack's instances are skinned and reach LDS after
         // them: their load round trip is hidden and one barrier separates the packs.  (Otherwise: staged between the
@@ -827,7 +815,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
                     // the image bit-for-bit unchanged: the skip needs no branch.
-                    for_row<F16, kRowAhead4>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
                         const v2f oxy = v2f{ox, oy};
@@ -835,7 +823,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                         for (int j = 0; j < kPack; ++j) { dxy[k][j] += oxy * w[j]; dz[k][j] += oz * w[j]; }
                     });
                 } else {
-                    for_row<F16, kRowAhead4>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
+                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
                         const v2f oxy = v2f{ox, oy};
@@ -1060,15 +1048,12 @@ __global__ __launch_bounds__(kThreads) void fill_kernel(float4 *dst, size_t n) {
 // and as the probe of mmdx_crowd_output_alloc().
 __global__ __launch_bounds__(kThreads) void pattern_fill_kernel(float4 *a, float4 *b, uint32_t nv,
                                                                 uint32_t ni, uint32_t ntiles, uint32_t bpva,
-                                                                uint32_t bpvb, uint32_t rotate) {
+                                                                uint32_t bpvb) {
     const uint32_t tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
     const uint32_t v0 = tile * kTileVerts, nvt = min(kTileVerts, nv - v0);
     const uint32_t pa = nvt * bpva / 16, pb = nvt * bpvb / 16;   // callers keep nv * bytes-per-vertex % 16 == 0
     const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
-    const uint32_t g_lo = grp * 16, g_n = min(ni, grp * 16 + 16) - g_lo;
-    const uint32_t rot = rotate ? (tile * 5u + grp * 3u) % g_n : 0u;
-    for (uint32_t k = 0; k < g_n; ++k) {
-        const uint32_t g = g_lo + (k + rot >= g_n ? k + rot - g_n : k + rot);
+    for (uint32_t g = grp * 16; g < min(ni, grp * 16 + 16); ++g) {
         const size_t base_a = (size_t(g) * nv + v0) * bpva / 16, base_b = (size_t(g) * nv + v0) * bpvb / 16;
         for (uint32_t q = threadIdx.x; q < pa + pb; q += kThreads) {
             store16(q < pa ? a + base_a + q : b + base_b + (q - pa), v);      // the deform kernel's store instruction (policy and all)
@@ -1215,10 +1200,10 @@ hipError_t MMDX_K(launch_morph_apply)(bool f16, const DeformParams &p, const Fla
 
 #ifndef MMDX_FAST_MATH
 hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, uint32_t bpva, uint32_t bpvb,
-                               hipStream_t stream, uint32_t rotate) {
+                               hipStream_t stream) {
     const uint32_t ntiles = (nv + kTileVerts - 1) / kTileVerts;
     hipLaunchKernelGGL(pattern_fill_kernel, dim3(ntiles * ((ni + 15) / 16)), dim3(kThreads), 0, stream,
-                       reinterpret_cast<float4 *>(a), reinterpret_cast<float4 *>(b), nv, ni, ntiles, bpva, bpvb, rotate);
+                       reinterpret_cast<float4 *>(a), reinterpret_cast<float4 *>(b), nv, ni, ntiles, bpva, bpvb);
     return hipGetLastError();
 }
 

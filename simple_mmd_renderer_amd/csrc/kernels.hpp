@@ -60,7 +60,6 @@ struct DeformParams {
     uint32_t out_aligned;        // out_a and out_b are 16-byte aligned
     uint32_t finite_offsets;     // every vertex-morph offset is finite (branch-free morph skip is exact)
     uint32_t interleave;         // crowd modes: instance = g*ngroups + grp instead of grp*group + g
-    uint32_t rotate;             // A/B knob: rotate every workgroup's instance order (see deform_kernel)
     uint32_t tile_order;         // MMDX_CREATE_TILE_ORDER: outputs in the engine's vertex order (tile-local class sort), stored straight
                                  // from registers -- no LDS image, no per-instance barrier
 };
@@ -90,7 +89,7 @@ hipError_t launch_morph_apply(bool f16, const DeformParams &p, const FlattenPara
                               hipStream_t stream);
 constexpr uint32_t kMaxFusedSlots = 8192;
 hipError_t launch_pattern_fill(void *a, void *b, uint32_t nv, uint32_t ni, uint32_t bpva, uint32_t bpvb,
-                               hipStream_t stream, uint32_t rotate = 0);
+                               hipStream_t stream);
 hipError_t launch_flatten(const FlattenParams &p, hipStream_t stream);
 hipError_t launch_morph_track_eval(const MorphTrackParams &t, hipStream_t stream);
 hipError_t launch_copy(void *dst, const void *src, size_t bytes, hipStream_t stream);

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
 
-KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_INTERLEAVE", "MMDX_SHARED_FUSED", "MMDX_EXPERIMENT_DIRECT", "MMDX_ROTATE")
+KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_INTERLEAVE", "MMDX_SHARED_FUSED", "MMDX_EXPERIMENT_DIRECT")
 
 
 def main():
