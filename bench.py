@@ -62,6 +62,8 @@ def launch_ranks(n: int, argv) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("OMP_NUM_THREADS", "1")
         mine = set(cpus[r * per:(r + 1) * per]) if per >= 1 else None
+        if mine:
+            env["MMDX_BENCH_PINNED"] = "1"          # (the rank must not slice its slice again)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                       preexec_fn=(lambda m=mine: os.sched_setaffinity(0, m)) if mine else None))
@@ -98,6 +100,17 @@ def main():
     # N > 1 without a launcher: decided before the product library is loaded or any HIP call is made.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    # Under an external launcher (torch.distributed.run) nobody pinned the ranks: take this rank's slice of the CPUs the job
+    # was given, as launch_ranks does for its own children (no-op for one rank or when the slice would be empty).
+    try:
+        lw, lr = int(os.environ.get("LOCAL_WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+        cpus = sorted(os.sched_getaffinity(0))
+        if (lw > 1 and os.environ.get("MMDX_BENCH_NO_AFFINITY") != "1" and os.environ.get("MMDX_BENCH_PINNED") != "1"
+                and len(cpus) >= 2 * lw):
+            per = len(cpus) // lw
+            os.sched_setaffinity(0, set(cpus[lr * per:(lr + 1) * per]))
+    except (OSError, ValueError):
+        pass
 
     from simple_mmd_renderer_amd.crowd import Rendezvous, crowd_frames, shard_instances
     if args.dry_run:
