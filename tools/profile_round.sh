@@ -7,7 +7,7 @@
 # 8. SQ counters of the rig kernels; 9. the single-frame kernels (trace + SQ counters).  Outputs in gpurun_out/<tag>/; tools/summarize_profiles.py condenses them.
 # rocprofv3 is always given the program itself after "--" (python3 ...), never a wrapper.
 set -e -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 from=${2:-1}            # 1: everything; 6: from the all-workloads trace on (stages 1-5 already collected)
 out=gpurun_out/$tag
 mkdir -p $out
