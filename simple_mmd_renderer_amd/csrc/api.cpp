@@ -303,7 +303,17 @@ void mmdx::morph_motion_release_device(MorphMotionDevice &d) {
     d.device = -1;
 }
 
+// A stream that is recording takes calls from the recording thread only: the "nothing may allocate / copy from the host / wait"
+// guards are per thread (thread-local capture mode), a call from another thread would slip past them.
+static mmdx_status recording_thread_check(mmdx_model_t model) {
+    if (model && model->capturing && model->capture_thread != std::this_thread::get_id())
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "this model's stream is recording a graph on another thread: recorded calls must come "
+                                               "from the thread that called mmdx_graph_begin");
+    return MMDX_OK;
+}
+
 mmdx_status mmdx::resolve_stream(mmdx_model_t model, int *device, hipStream_t *stream) {
+    if (mmdx_status st = recording_thread_check(model)) return st;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(MMDX_ERR_NO_DEVICE, "no HIP device available (motion and rig evaluation run on the GPU)");
@@ -521,6 +531,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (!host_direct_enabled()) map_a = map_b = nullptr;
     }
     if (m->capturing) {
+        if (mmdx_status rst = recording_thread_check(m)) return rst;
         const uint32_t need = MMDX_PALETTE_ON_DEVICE | MMDX_OUT_ON_DEVICE | (p.ns ? uint32_t(MMDX_WEIGHTS_ON_DEVICE) : 0u);
         if ((a->flags & need) != need)
             return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory");
@@ -843,6 +854,7 @@ mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, u
         return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or n_instances == 0");
     if (tl_recording_depth > 0 && (flags & (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE)) != (MMDX_FRAMES_ON_DEVICE | MMDX_OUT_ON_DEVICE))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "while a graph is being recorded every operand must be in device memory");
+    if (mmdx_status rst = recording_thread_check(model)) return rst;
     const MorphMotionHost h = morph_motion_host(mm);
     MorphMotionDevice &d = morph_motion_device(mm);
     int n = 0;

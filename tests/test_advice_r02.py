@@ -189,6 +189,13 @@ def test_graph_pins_its_handles(oracle, hip_lib):
     t = threading.Thread(target=lambda: err.append(_try(lambda: dm.graph_end())))
     t.start(); t.join()
     assert isinstance(err[0], api.MmdxError) and "thread" in str(err[0])
+    # ... and so is a RECORDED call from another thread (the per-thread "nothing may allocate" guards would not see it)
+    for call in (lambda: dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags),
+                 lambda: sk.solve_device(ni, d_pose.ptr, d_pal.ptr, dm)):
+        err = []
+        t = threading.Thread(target=lambda c=call: err.append(_try(c)))
+        t.start(); t.join()
+        assert isinstance(err[0], api.MmdxError) and "another thread" in str(err[0]), err
     g = dm.graph_end()
     # (2) a larger crowd would have to grow the model's slot-weight scratch (which the graph holds): refused, with a reason
     with pytest.raises(api.MmdxError, match="recorded"):
