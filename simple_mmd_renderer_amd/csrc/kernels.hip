@@ -72,6 +72,9 @@ __device__ __forceinline__ unsigned short f2h(float x) {
 #ifndef MMDX_STORE_POLICY
 #define MMDX_STORE_POLICY 1
 #endif
+#ifndef MMDX_WALK_ZPAIR
+#define MMDX_WALK_ZPAIR 0          // build-time A/B knob of the per-instance-morph walk (see there)
+#endif
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(float4 *dst, const float4 v) {
 #if MMDX_STORE_POLICY == 1
@@ -819,8 +822,20 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                         float w[kPack];
                         weights(slot, w);
                         const v2f oxy = v2f{ox, oy};
+#if MMDX_WALK_ZPAIR
+                        // z of two instances per packed instruction: (dz_j, dz_j+1) += (oz, oz) * (w_j, w_j+1) -- the weights of
+                        // an instance quad arrive as such pairs, and each half is the same IEEE mul / add as before
+                        const v2f ozz = v2f{oz, oz};
+#pragma unroll
+                        for (int j = 0; j < kPack; j += 2) {
+                            dxy[k][j] += oxy * w[j]; dxy[k][j + 1] += oxy * w[j + 1];
+                            const v2f zz = v2f{dz[k][j], dz[k][j + 1]} + ozz * v2f{w[j], w[j + 1]};
+                            dz[k][j] = zz.x; dz[k][j + 1] = zz.y;
+                        }
+#else
 #pragma unroll
                         for (int j = 0; j < kPack; ++j) { dxy[k][j] += oxy * w[j]; dz[k][j] += oz * w[j]; }
+#endif
                     });
                 } else {
                     for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
