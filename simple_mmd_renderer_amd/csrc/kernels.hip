@@ -73,7 +73,7 @@ __device__ __forceinline__ unsigned short f2h(float x) {
 #define MMDX_STORE_POLICY 1
 #endif
 #ifndef MMDX_WALK_ZPAIR
-#define MMDX_WALK_ZPAIR 0          // build-time A/B knob of the per-instance-morph walk (see there)
+#define MMDX_WALK_ZPAIR 1          // build-time A/B knob of the per-instance-morph walk (see there): z-pairing on (round 3: -2 % config 5 x 64, -1.5 % config 2 x 64, config 3' even; profiles/r03/walk_zpair_ab.txt)
 #endif
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(float4 *dst, const float4 v) {
