@@ -17,9 +17,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("MMDX_BUILD_OUT") or os.path.join(HERE, "libmmdx.so")   # MMDX_BUILD_OUT: experiment builds (tools/)
-SOURCES = ["api.cpp", "kernels.hip", "kernels_fast.hip", "plan.cpp", "pmx.cpp", "pmd.cpp", "vmd.cpp", "error.cpp",
+SOURCES = ["api.cpp", "bench_api.cpp", "kernels.hip", "kernels_fast.hip", "plan.cpp", "pmx.cpp", "pmd.cpp", "vmd.cpp", "error.cpp",
            "rig.cpp", "rig_api.cpp", "rig_kernels.hip"]
-HEADERS = ["kernels.hpp", "plan.hpp", "error.hpp", "vmd.hpp", "rig.hpp", "rig_kernels.hpp", "pmx.hpp", "graph_pin.hpp",
+HEADERS = ["kernels.hpp", "plan.hpp", "error.hpp", "vmd.hpp", "rig.hpp", "rig_kernels.hpp", "pmx.hpp", "graph_pin.hpp", "api_internal.hpp",
            os.path.join("..", "..", "include", "mmdx.h"), os.path.join("..", "..", "include", "mmdx_bench.h")]
 ARCH = "gfx950"
 

@@ -17,13 +17,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/mmdx.h"
-#include "../../include/mmdx_bench.h"
-#include "error.hpp"
-#include "graph_pin.hpp"
-#include "kernels.hpp"
-#include "plan.hpp"
-#include "rig_kernels.hpp"
+#include "api_internal.hpp"
 
 using namespace mmdx;
 
@@ -38,51 +32,12 @@ int current_device() { return tl_device >= 0 ? tl_device : g_default_device.load
 std::once_flag g_prepare_once[16];
 hipError_t g_prepare_status[16];
 
-mmdx_status hip_fail(hipError_t e, const char *what) {
-    // leave no sticky error behind for the next call
-    (void)hipGetLastError();
-    // the two refusals of DevBuf::ensure / rig_api's Buf::ensure (no HIP call failed)
-    if (e == hipErrorIllegalState)
-        return fail(MMDX_ERR_INVALID_ARGUMENT, std::string(what) + ": a scratch buffer of this handle would have to grow, but a recorded "
-                    "graph (mmdx_graph_*) holds its address -- destroy the graph first, or size the buffers with an un-recorded call of "
-                    "the largest shape before recording");
-    if (e == hipErrorStreamCaptureUnsupported)
-        return fail(MMDX_ERR_INVALID_ARGUMENT, std::string(what) + ": this call would have to allocate device memory while a graph is "
-                    "being recorded -- run the same sequence once un-recorded first");
-    return fail(e == hipErrorOutOfMemory ? MMDX_ERR_OUT_OF_MEMORY
-                                         : (e == hipErrorNoDevice ? MMDX_ERR_NO_DEVICE : MMDX_ERR_HIP),
-                std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")");
-}
 
-#define HIP_TRY(expr)                                          \
-    do {                                                       \
-        hipError_t e_ = (expr);                                \
-        if (e_ != hipSuccess) return hip_fail(e_, #expr);      \
-    } while (0)
 
 // Streams of this thread that are recording a graph (hipStreamCaptureModeThreadLocal: begin and end happen on one thread,
 // mmdx_graph_end enforces it): while > 0 nothing on this thread may allocate, copy from the host or wait.
 thread_local int tl_recording_depth = 0;
 
-struct DevBuf {
-    void *ptr = nullptr;
-    size_t bytes = 0;
-    const GraphPin *pin = nullptr;           // per-call scratch of a handle: may not move while a recorded graph holds it
-    hipError_t ensure(size_t need) {
-        if (need <= bytes) return hipSuccess;
-        if (tl_recording_depth > 0) return hipErrorStreamCaptureUnsupported;   // run the sequence once un-captured first
-        if (graph_pinned(pin)) return hipErrorIllegalState;
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&ptr, need);
-        if (e == hipSuccess) bytes = need;
-        return e;
-    }
-    void release() {
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr; bytes = 0;
-    }
-};
 
 template <typename T>
 hipError_t upload(DevBuf &b, const std::vector<T> &v, uint64_t &total) {
@@ -96,37 +51,6 @@ hipError_t upload(DevBuf &b, const std::vector<T> &v, uint64_t &total) {
 
 }  // namespace
 
-struct mmdx_model_s {
-    Plan plan;
-    int device = -1;  // -1: host-only
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    // per-call kernel timing (mmdx_profile_*): event quadruples {skin0, skin1, morph0, morph1},
-    // recorded on the launch stream without any host sync; read back by mmdx_profile_collect
-    std::vector<hipEvent_t> prof_events;
-    std::vector<uint8_t> prof_has_morph;
-    size_t prof_calls = 0;
-    bool profile = false;
-    uint32_t profile_stride = 1, prof_seen = 0;     // time every profile_stride-th call
-    uint64_t device_bytes = 0;
-    // static streams
-    DevBuf tiles, spos, snrm, suv, perm, skin1, skin2_ids, skin2_w, skin4_ids, skin4_w, bone_list,
-        ell, entries, slot_top, chain_off, chain_rate;
-    // per-call scratch (grown on demand, reused)
-    DevBuf pal, rates, wslot, morphed, out_a, out_b;
-    bool morphed_valid = false;     // `morphed` holds the result of a shared morph pass (MMDX_MORPH_UNCHANGED)
-    bool capturing = false;         // between mmdx_graph_begin and mmdx_graph_end: the stream records
-    std::thread::id capture_thread; // ... begun on this thread (thread-local capture mode: it must end there too)
-    GraphPin pin;                   // graphs that hold addresses of this model's scratch buffers
-    std::vector<GraphPin *> rec_pins;   // handles that took part in the recording in progress (incl. this model)
-    mmdx_model_s() {
-        for (DevBuf *b : {&pal, &rates, &wslot, &morphed, &out_a, &out_b}) b->pin = &pin;
-    }
-    // page-locked bounce buffer for small outputs bound for pageable host memory (see mmdx_deform_batched)
-    void *bounce = nullptr, *bounce_dev = nullptr;  // host address, device-side address
-    size_t bounce_bytes = 0;
-    void *bounce_in = nullptr;                     // the same for small pageable inputs (palette, rates)
-};
 
 struct mmdx_graph_s {
     void *exec = nullptr;      // hipGraphExec_t
@@ -141,10 +65,19 @@ std::mutex g_graph_mu;          // graph <-> handle links (rare operations: reco
 }
 void mmdx::graph_note_handle(mmdx_model_s *model, GraphPin *pin) {
     if (!model || !model->capturing || !pin) return;
-    if (std::find(model->rec_pins.begin(), model->rec_pins.end(), pin) == model->rec_pins.end()) model->rec_pins.push_back(pin);
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    if (std::find(model->rec_pins.begin(), model->rec_pins.end(), pin) == model->rec_pins.end()) {
+        model->rec_pins.push_back(pin);
+        pin->recorders.push_back(model);
+    }
 }
 void mmdx::graph_drop_handle(GraphPin *pin) {
     std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (mmdx_model_s *rec : pin->recorders) {        // a recording in progress used this handle: it can no longer become a graph
+        rec->rec_pins.erase(std::remove(rec->rec_pins.begin(), rec->rec_pins.end(), pin), rec->rec_pins.end());
+        rec->rec_poisoned = true;
+    }
+    pin->recorders.clear();
     for (mmdx_graph_s *g : pin->graphs) {
         g->valid.store(false, std::memory_order_release);
         g->pins.erase(std::remove(g->pins.begin(), g->pins.end(), pin), g->pins.end());
@@ -213,30 +146,7 @@ hipError_t copy_in(mmdx_model_s *m, void *dst, const void *src, PtrKind kind, si
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
 }
 
-int env_int(const char *name, int dflt) {
-    const char *s = std::getenv(name);
-    return s && *s ? std::atoi(s) : dflt;
-}
 
-// Launch-shape overrides for A/B runs (tools/): read ONCE, at the first deform call of the process -- the
-// per-frame call has a budget of a few microseconds and getenv walks the whole environment.
-struct LaunchOverrides {
-    int interleave, threads, lds_target, group, placement_log, placement_park;
-    int frame_kernel;   // MMDX_FRAME_KERNEL: 0 = a single frame always runs the tile kernel, 1 = models of fewer than 256 tiles run the
-                        // frame kernel (default), 2 = always (A/B); MMDX_FRAME_THREADS: 128 / 256 lanes per workgroup
-    int frame_threads;
-    int shared_fused;   // MMDX_SHARED_FUSED: crowds with a shared facial state gather the morphs inside the deform kernel: 0 never,
-                        // 1 up to 8 instances (default), 2 always (A/B, tests)
-};
-LaunchOverrides read_launch_overrides() {
-    return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
-            env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
-            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1)};
-}
-LaunchOverrides &launch_overrides() {
-    static LaunchOverrides o = read_launch_overrides();
-    return o;
-}
 
 mmdx_status upload_model(mmdx_model_s *m) {
     Plan &p = m->plan;
@@ -291,6 +201,39 @@ size_t out_bytes_b(uint32_t layout, uint64_t nvi) {
 }
 
 }  // namespace
+
+
+// ---- shared with bench_api.cpp (api_internal.hpp) -----------------------------------------------------------------------
+mmdx_status mmdx::hip_fail(hipError_t e, const char *what) {
+    // leave no sticky error behind for the next call
+    (void)hipGetLastError();
+    // the two refusals of DevBuf::ensure / rig_api's Buf::ensure (no HIP call failed)
+    if (e == hipErrorIllegalState)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, std::string(what) + ": a scratch buffer of this handle would have to grow, but a recorded "
+                    "graph (mmdx_graph_*) holds its address -- destroy the graph first, or size the buffers with an un-recorded call of "
+                    "the largest shape before recording");
+    if (e == hipErrorStreamCaptureUnsupported)
+        return fail(MMDX_ERR_INVALID_ARGUMENT, std::string(what) + ": this call would have to allocate device memory while a graph is "
+                    "being recorded -- run the same sequence once un-recorded first");
+    return fail(e == hipErrorOutOfMemory ? MMDX_ERR_OUT_OF_MEMORY
+                                         : (e == hipErrorNoDevice ? MMDX_ERR_NO_DEVICE : MMDX_ERR_HIP),
+                std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")");
+}
+
+int mmdx::env_int(const char *name, int dflt) {
+    const char *s = std::getenv(name);
+    return s && *s ? std::atoi(s) : dflt;
+}
+
+LaunchOverrides mmdx::read_launch_overrides() {
+    return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
+            env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
+            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1)};
+}
+LaunchOverrides &mmdx::launch_overrides() {
+    static LaunchOverrides o = read_launch_overrides();
+    return o;
+}
 
 void mmdx::morph_motion_release_device(MorphMotionDevice &d) {
     graph_drop_handle(&d.pin);               // graphs that hold these addresses can no longer be replayed
@@ -435,6 +378,13 @@ mmdx_status mmdx_model_create(const mmdx_model_desc *desc, mmdx_model_t *out_mod
 
 mmdx_status mmdx_model_destroy(mmdx_model_t model) {
     if (!model) return MMDX_OK;
+    if (model->capturing) {              // destroyed in the middle of a recording: end it here so that no state is left behind
+        if (model->capture_thread != std::this_thread::get_id())
+            return fail(MMDX_ERR_INVALID_ARGUMENT, "this model is recording a graph on another thread: end the recording there first");
+        mmdx_graph_t dropped = nullptr;
+        (void)mmdx_graph_end(model, &dropped);
+        mmdx_graph_destroy(dropped);
+    }
     if (model->device >= 0) {
         (void)hipSetDevice(model->device);
         (void)hipStreamSynchronize(model->stream);
@@ -801,51 +751,6 @@ mmdx_status mmdx_sync(mmdx_model_t m) {
     return MMDX_OK;
 }
 
-mmdx_status mmdx_timer_start(mmdx_model_t m) {
-    if (!m || m->device < 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
-    HIP_TRY(hipEventRecord(m->ev_t0, m->stream));
-    return MMDX_OK;
-}
-
-mmdx_status mmdx_timer_stop(mmdx_model_t m, float *ms) {
-    if (!m || m->device < 0 || !ms) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
-    HIP_TRY(hipEventRecord(m->ev_t1, m->stream));
-    HIP_TRY(hipEventSynchronize(m->ev_t1));
-    HIP_TRY(hipEventElapsedTime(ms, m->ev_t0, m->ev_t1));
-    return MMDX_OK;
-}
-
-mmdx_status mmdx_profile_enable(mmdx_model_t m, int32_t enabled) {
-    if (!m || m->device < 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "model is NULL or host-only");
-    m->profile = enabled != 0;
-    m->profile_stride = enabled > 1 ? uint32_t(enabled) : 1u;
-    m->prof_seen = 0;
-    m->prof_calls = 0;
-    return MMDX_OK;
-}
-
-mmdx_status mmdx_profile_collect(mmdx_model_t m, uint32_t *n_calls, float *skin_ms_total,
-                                 float *morph_ms_total) {
-    if (!m || m->device < 0 || !n_calls || !skin_ms_total || !morph_ms_total)
-        return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument or host-only model");
-    double skin = 0.0, morph = 0.0;
-    for (size_t c = 0; c < m->prof_calls; ++c) {
-        hipEvent_t *ev = m->prof_events.data() + 4 * c;
-        float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(ev[1]));
-        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
-        skin += ms;
-        if (m->prof_has_morph[c]) {
-            HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
-            morph += ms;
-        }
-    }
-    *n_calls = uint32_t(m->prof_calls);
-    *skin_ms_total = float(skin);
-    *morph_ms_total = float(morph);
-    m->prof_calls = 0;
-    return MMDX_OK;
-}
 
 // ---- VMD morph motion: device-side evaluation ----------------------------------------------------
 mmdx_status mmdx_morph_motion_eval(mmdx_morph_motion_t mm, mmdx_model_t model, uint32_t n_instances,
@@ -928,7 +833,12 @@ mmdx_status mmdx_graph_begin(mmdx_model_t m) {
     HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
     m->capturing = true;
     m->capture_thread = std::this_thread::get_id();
-    m->rec_pins.assign(1, &m->pin);
+    m->rec_poisoned = false;
+    {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        m->rec_pins.assign(1, &m->pin);
+        m->pin.recorders.push_back(m);
+    }
     ++tl_recording_depth;
     return MMDX_OK;
 }
@@ -943,9 +853,22 @@ mmdx_status mmdx_graph_end(mmdx_model_t m, mmdx_graph_t *out) {
         return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_graph_end must be called on the thread that called mmdx_graph_begin");
     m->capturing = false;
     --tl_recording_depth;
+    std::vector<GraphPin *> used;
+    bool poisoned;
+    {   // the recording is over either way: its handles no longer count this model as a recorder
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        used.swap(m->rec_pins);
+        for (GraphPin *p : used) p->recorders.erase(std::remove(p->recorders.begin(), p->recorders.end(), m), p->recorders.end());
+        poisoned = m->rec_poisoned;
+    }
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(m->stream, &g);
     if (e != hipSuccess || !g) return hip_fail(e != hipSuccess ? e : hipErrorUnknown, "hipStreamEndCapture (a recorded call failed?)");
+    if (poisoned) {
+        (void)hipGraphDestroy(g);
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "a skeleton or motion used by this recording was destroyed before mmdx_graph_end: "
+                                               "the recording holds freed device addresses and is discarded");
+    }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
@@ -955,13 +878,12 @@ mmdx_status mmdx_graph_end(mmdx_model_t m, mmdx_graph_t *out) {
     gr->exec = exec; gr->stream = m->stream; gr->device = m->device;
     {   // pin every handle whose buffers the recorded calls referred to
         std::lock_guard<std::mutex> lk(g_graph_mu);
-        gr->pins = m->rec_pins;
+        gr->pins = used;
         for (GraphPin *p : gr->pins) {
             p->graphs.push_back(gr);
             p->pins.fetch_add(1, std::memory_order_acq_rel);
         }
     }
-    m->rec_pins.clear();
     *out = gr;
     return MMDX_OK;
 }
@@ -1034,73 +956,15 @@ mmdx_status mmdx_device_memset(void *dst, int value, size_t bytes) {
     return MMDX_OK;
 }
 
-void mmdx_debug_reload_env(void) { launch_overrides() = read_launch_overrides(); }
+
 
 mmdx_status mmdx_device_synchronize(void) {
     HIP_TRY(hipDeviceSynchronize());
     return MMDX_OK;
 }
 
-static mmdx_status bench_stream_op(void *dst, const void *src, size_t bytes, int32_t iters, float *avg_ms) {
-    if (!dst || !avg_ms || iters <= 0 || bytes < 16) return fail(MMDX_ERR_INVALID_ARGUMENT, "bad argument");
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    hipError_t e = src ? launch_copy(dst, src, bytes, nullptr) : launch_fill(dst, bytes, nullptr);  // warm-up
-    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters && e == hipSuccess; ++i)
-        e = src ? launch_copy(dst, src, bytes, nullptr) : launch_fill(dst, bytes, nullptr);
-    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (e != hipSuccess) return hip_fail(e, "bench stream op");
-    *avg_ms = ms / float(iters);
-    return MMDX_OK;
-}
 
-mmdx_status mmdx_bench_copy(void *dst, const void *src, size_t bytes, int32_t iters, float *avg_ms) {
-    if (!src) return fail(MMDX_ERR_INVALID_ARGUMENT, "src is NULL");
-    return bench_stream_op(dst, src, bytes, iters, avg_ms);
-}
 
-mmdx_status mmdx_bench_fill(void *dst, size_t bytes, int32_t iters, float *avg_ms) {
-    return bench_stream_op(dst, nullptr, bytes, iters, avg_ms);
-}
-
-namespace {
-// average ms of `iters` store-pattern launches on the default stream (after one warm-up launch)
-hipError_t time_store_pattern(void *a, void *b, uint32_t nv, uint32_t ni, uint32_t bpva, uint32_t bpvb, int iters,
-                              float *avg_ms) {
-    hipEvent_t e0, e1;
-    hipError_t e = hipEventCreate(&e0);
-    if (e != hipSuccess) return e;
-    e = hipEventCreate(&e1);
-    if (e != hipSuccess) { (void)hipEventDestroy(e0); return e; }
-    e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr);
-    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_pattern_fill(a, b, nv, ni, bpva, bpvb, nullptr);
-    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *avg_ms = ms / float(iters);
-    return e;
-}
-}  // namespace
-
-mmdx_status mmdx_bench_store_pattern(void *out_a, void *out_b, uint32_t n_vertices, uint32_t n_instances,
-                                     int32_t iters, float *avg_ms) {
-    if (!out_a || !out_b || !avg_ms || iters <= 0 || !n_vertices || !n_instances || (n_vertices & 3))
-        return fail(MMDX_ERR_INVALID_ARGUMENT, "bad argument (n_vertices must be a multiple of 4)");
-    hipError_t e = time_store_pattern(out_a, out_b, n_vertices, n_instances, 12, 12, iters, avg_ms);
-    if (e != hipSuccess) return hip_fail(e, "bench store pattern");
-    return MMDX_OK;
-}
 
 mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_t out_layout, uint32_t max_tries,
                                     void **out_a, void **out_b, mmdx_placement_info *info) {

@@ -17,6 +17,7 @@ namespace mmdx {
 struct GraphPin {
     std::atomic<int> pins{0};             // live graphs that hold addresses of this handle's buffers
     std::vector<mmdx_graph_s *> graphs;   // guarded by the registry's mutex (api.cpp)
+    std::vector<mmdx_model_s *> recorders;   // models whose recording IN PROGRESS has used this handle (same mutex)
 };
 
 // A library call is about to enqueue work of `pin`'s handle on `model`'s stream: if that stream is recording, the

@@ -217,6 +217,17 @@ def test_graph_pins_its_handles(oracle, hip_lib):
     with pytest.raises(api.MmdxError, match="destroyed"):
         g2.launch()
     g2.close()
+    # (4) a handle destroyed DURING a recording that used it: the recording cannot become a graph
+    sk2 = vmd.Skeleton(m.bone_pos, np.asarray(m.bone_parent, np.int32))
+    sk2.solve_device(ni, d_pose.ptr, d_pal.ptr, dm)
+    dm.sync()
+    dm.graph_begin()
+    sk2.solve_device(ni, d_pose.ptr, d_pal.ptr, dm)
+    sk2.close()
+    with pytest.raises(api.MmdxError, match="destroyed before"):
+        dm.graph_end()
+    dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)    # the model is usable again
+    dm.sync()
     dm.graph_begin()
     dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
     g3 = dm.graph_end()
@@ -224,6 +235,16 @@ def test_graph_pins_its_handles(oracle, hip_lib):
     with pytest.raises(api.MmdxError, match="destroyed"):
         g3.launch()
     g3.close()
+    # (5) a model destroyed in the middle of its own recording leaves no recording state behind on this thread
+    dm2 = DeformModel(m)
+    dm2.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+    dm2.sync()
+    dm2.graph_begin()
+    dm2.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags)
+    dm2.close()
+    with DeformModel(m) as dm3:                      # allocating calls work again (nothing thinks this thread still records)
+        pos, _ = dm3.deform_batched(rates[:ni], synth.make_palettes(m, np.arange(ni)))
+        assert np.isfinite(pos).all()
     for b in (d_fr, d_pose, d_pal, d_w, d_a, d_b):
         b.free()
 
