@@ -239,7 +239,7 @@ void mmdx::morph_motion_release_device(MorphMotionDevice &d) {
     graph_drop_handle(&d.pin);               // graphs that hold these addresses can no longer be replayed
     if (d.device >= 0) (void)hipSetDevice(d.device);
     for (void **p : {&d.key_off, &d.frames, &d.weights, &d.frames_in, &d.out}) {
-        if (*p) (void)hipFree(*p);
+        device_free_or_defer(*p);
         *p = nullptr;
     }
     d.frames_in_bytes = d.out_bytes = 0;
@@ -268,6 +268,14 @@ mmdx_status mmdx::resolve_stream(mmdx_model_t model, int *device, hipStream_t *s
 }
 mmdx_status mmdx::hip_status(hipError_t e, const char *what) { return hip_fail(e, what); }
 bool mmdx::graph_recording() { return tl_recording_depth > 0; }
+// hipFree is one of the calls the runtime refuses on a thread whose stream is recording (it would also invalidate the recording):
+// a handle destroyed in that window parks its blocks here, mmdx_graph_end frees them.
+static thread_local std::vector<void *> tl_deferred_free;
+void mmdx::device_free_or_defer(void *ptr) {
+    if (!ptr) return;
+    if (tl_recording_depth > 0) tl_deferred_free.push_back(ptr);
+    else (void)hipFree(ptr);
+}
 
 // The wait at the end of a call that hands results back to the host.  A per-frame call is tens of
 // microseconds of device work; hipStreamSynchronize may put the thread to sleep and then pays a wake-up that is
@@ -863,12 +871,17 @@ mmdx_status mmdx_graph_end(mmdx_model_t m, mmdx_graph_t *out) {
     }
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(m->stream, &g);
-    if (e != hipSuccess || !g) return hip_fail(e != hipSuccess ? e : hipErrorUnknown, "hipStreamEndCapture (a recorded call failed?)");
+    if (tl_recording_depth == 0) {                      // blocks of handles destroyed while this thread was recording
+        for (void *p : tl_deferred_free) (void)hipFree(p);
+        tl_deferred_free.clear();
+    }
     if (poisoned) {
-        (void)hipGraphDestroy(g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
         return fail(MMDX_ERR_INVALID_ARGUMENT, "a skeleton or motion used by this recording was destroyed before mmdx_graph_end: "
                                                "the recording holds freed device addresses and is discarded");
     }
+    if (e != hipSuccess || !g) return hip_fail(e != hipSuccess ? e : hipErrorUnknown, "hipStreamEndCapture (a recorded call failed?)");
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);

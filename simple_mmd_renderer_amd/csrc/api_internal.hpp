@@ -44,7 +44,7 @@ struct DevBuf {
         return e;
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        device_free_or_defer(ptr);
         ptr = nullptr; bytes = 0;
     }
 };

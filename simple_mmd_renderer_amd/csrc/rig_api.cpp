@@ -47,7 +47,7 @@ struct Buf {
         return hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        device_free_or_defer(ptr);
         ptr = nullptr; bytes = 0;
     }
 };

@@ -23,6 +23,8 @@ mmdx_status resolve_stream(mmdx_model_t model, int *device, hipStream_t *stream)
 mmdx_status hip_status(hipError_t e, const char *what);
 // api.cpp: the calling thread is between mmdx_graph_begin and mmdx_graph_end (nothing may allocate, copy from the host or wait)
 bool graph_recording();
+// api.cpp: hipFree, or -- while this thread records a graph, when the runtime refuses frees -- parked until mmdx_graph_end
+void device_free_or_defer(void *ptr);
 // api.cpp: host-visible completion of the work queued on `stream` (see there).
 hipError_t wait_stream(hipStream_t stream);
 
