@@ -238,19 +238,6 @@ def main():
     # on otherwise identical runs); all three are kept in roofline.kernel_only_batches_ms.
     kernel_batches = [timed_batch(kernel_only_step, args.steps) for _ in range(3)]
     kernel_ms = sorted(kernel_batches)[1]
-    # ---- opt-in MMDX_MORPH_AHEAD (the rates ARE final in device memory here): the shared morph pass of step k+1 on the handle's
-    # side stream under step k's deform kernel; same K steps, same wall-clock bracket.  An extra, not the headline. ------------
-    def ahead_step():
-        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout, flags | api.MORPH_AHEAD, pos_scale)
-    for _ in range(args.warmup):
-        ahead_step()
-    device_synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ahead_step()
-    device_synchronize()
-    ahead_ms = (time.perf_counter() - t0) / args.steps * 1e3
-    step()                                   # back to the plain form (and real results in the buffers)
     # ---- the old figure, kept as a named extra: events around every kernel of K more steps ---------------------
     dm.profile_enable(True)
     for _ in range(args.steps):
@@ -295,15 +282,12 @@ def main():
                      "step_event_ms": ev_ms / args.steps,
                      # W warm-up + K steps right after set-up, no settle batches in front (max over ranks, wall clock)
                      "cold": {"ms_per_step": cold_ms, "step_frac": step_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                     # opt-in MMDX_MORPH_AHEAD (morph pass of the next step on a side stream); rank 0's clock
-                     "morph_ahead": {"ms_per_step": ahead_ms, "step_frac": step_bytes / (ahead_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      # per-kernel events on every launch (round 1's headline; flatters the kernel, see above)
                      "event_bracketed_kernel_ms": skin_avg, "event_bracketed_morph_pass_ms": morph_avg,
                      "event_bracketed_frac": deform_bytes / (skin_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      # deform-kernel launches after the timed region, oldest first (trace post-processing)
                      "trace_segments": [["timed", args.steps], ["kernel_only", args.steps], ["kernel_only", args.steps],
-                                        ["kernel_only", args.steps], ["morph_ahead", args.warmup + args.steps + 1],
-                                        ["event_bracketed", args.steps]],
+                                        ["kernel_only", args.steps], ["event_bracketed", args.steps]],
                      "output_placement": placement,
                      "kernel_source_sha": kernel_source_sha(),
                      "settle_batches_step_ms": [round(x, 4) for x in settle_batches]},

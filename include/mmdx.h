@@ -150,15 +150,7 @@ enum {
                                          previous such call on this model (a crowd whose facial state
                                          changes less often than its poses): the morphed positions of that
                                          call are reused and the morph pass is skipped; morph_weights is
-                                         not read.  An error without such an earlier call.            */,
-    MMDX_MORPH_AHEAD = 1u << 5        /* OPT-IN, with MMDX_WEIGHTS_SHARED | MMDX_WEIGHTS_ON_DEVICE and NI > 8: the caller promises
-                                         that morph_weights is FINAL in device memory when this call is made (not produced by
-                                         work still queued on the model's stream).  The shared morph pass then runs on a side
-                                         stream of the handle into the second of two position buffers, next to whatever the
-                                         model's stream is still executing (the previous step's deform kernel), and only the
-                                         deform kernel waits for it.  Same results; takes the ~8 us morph pass and its two
-                                         kernel boundaries off a back-to-back stream of crowd steps.  Ignored while a graph is
-                                         being recorded.                                                             */
+                                         not read.  An error without such an earlier call.            */
 };
 
 typedef struct mmdx_deform_args {

@@ -18,7 +18,7 @@ ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5:
 
 CREATE_NORMALIZE, CREATE_HOST_ONLY, CREATE_F16_POSITIONS, CREATE_FAST_MATH, CREATE_TILE_ORDER = 1, 2, 4, 8, 16
 OUT_SOA, OUT_VERTEX32, OUT_SOA_POS16 = 0, 1, 2
-PALETTE_ON_DEVICE, WEIGHTS_ON_DEVICE, OUT_ON_DEVICE, WEIGHTS_SHARED, MORPH_UNCHANGED, MORPH_AHEAD = 1, 2, 4, 8, 16, 32
+PALETTE_ON_DEVICE, WEIGHTS_ON_DEVICE, OUT_ON_DEVICE, WEIGHTS_SHARED, MORPH_UNCHANGED = 1, 2, 4, 8, 16
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

@@ -181,11 +181,8 @@ void free_model(mmdx_model_s *m) {
         for (DevBuf *b : {&m->tiles, &m->spos, &m->snrm, &m->suv, &m->perm, &m->skin1, &m->skin2_ids,
                           &m->skin2_w, &m->skin4_ids, &m->skin4_w, &m->bone_list, &m->ell,
                           &m->entries, &m->slot_top, &m->chain_off, &m->chain_rate, &m->pal, &m->rates,
-                          &m->wslot, &m->morphed, &m->morphed_alt, &m->out_a, &m->out_b})
+                          &m->wslot, &m->morphed, &m->out_a, &m->out_b})
             b->release();
-        for (hipEvent_t ev : {m->ev_morph_done, m->ev_read[0], m->ev_read[1]})
-            if (ev) (void)hipEventDestroy(ev);
-        if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
         if (m->bounce) (void)hipHostFree(m->bounce);
         if (m->bounce_in) (void)hipHostFree(m->bounce_in);
         for (hipEvent_t ev : {m->ev_t0, m->ev_t1})
@@ -465,8 +462,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     const Plan &p = m->plan;
     const uint32_t ni = a->n_instances, layout = a->out_layout;
     if (ni == 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "n_instances must be >= 1");
-    if (a->flags & ~uint32_t(MMDX_PALETTE_ON_DEVICE | MMDX_WEIGHTS_ON_DEVICE | MMDX_OUT_ON_DEVICE | MMDX_WEIGHTS_SHARED | MMDX_MORPH_UNCHANGED |
-                             MMDX_MORPH_AHEAD))
+    if (a->flags & ~uint32_t(MMDX_PALETTE_ON_DEVICE | MMDX_WEIGHTS_ON_DEVICE | MMDX_OUT_ON_DEVICE | MMDX_WEIGHTS_SHARED | MMDX_MORPH_UNCHANGED))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown bits in mmdx_deform_args.flags");
     if (layout > MMDX_OUT_SOA_POS16) return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown out_layout");
     if (p.f16 != (layout == MMDX_OUT_SOA_POS16))
@@ -584,29 +580,9 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         f.out = static_cast<float *>(m->wslot.ptr);
         if (pev) HIP_TRY(hipEventRecord(pev[2], st));
         dp.wslot = f.out;
-        // MMDX_MORPH_AHEAD: the pass runs on the side stream into the buffer the most recent deform kernel does NOT read
-        const bool ahead = morph == kMorphShared && !unchanged && p.ns <= kMaxFusedSlots && (a->flags & MMDX_MORPH_AHEAD) &&
-                           (a->flags & MMDX_WEIGHTS_ON_DEVICE) && !m->capturing && !pev;
-        if (ahead) {
-            if (!m->side_stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
-                for (hipEvent_t *ev : {&m->ev_morph_done, &m->ev_read[0], &m->ev_read[1]})
-                    HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-            }
-            HIP_TRY(m->morphed_alt.ensure(size_t(p.nv) * 12));
-            const uint32_t nxt = m->morph_cur ^ 1u;
-            if (m->ev_read_set[nxt]) HIP_TRY(hipStreamWaitEvent(m->side_stream, m->ev_read[nxt], 0));   // its last reader is through
-            dp.morphed = static_cast<float *>(nxt ? m->morphed_alt.ptr : m->morphed.ptr);
-            HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, &f, m->side_stream));
-            HIP_TRY(hipEventRecord(m->ev_morph_done, m->side_stream));
-            HIP_TRY(hipStreamWaitEvent(st, m->ev_morph_done, 0));                                       // only the deform kernel waits
-            m->morph_cur = nxt;
-        }
-        dp.morphed = static_cast<float *>(m->morph_cur ? m->morphed_alt.ptr : m->morphed.ptr);
-        if (ahead) {
-            // launched above
-        } else if (morph == kMorphShared && unchanged) {
-            // nothing to launch: the current buffer holds the positions
+        dp.morphed = static_cast<float *>(m->morphed.ptr);
+        if (morph == kMorphShared && unchanged) {
+            // nothing to launch: `morphed` holds the positions
         } else if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
             HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, &f, st));      // flatten fused in: one launch
         } else if (morph == kMorphFused1) {
@@ -723,10 +699,6 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         HIP_TRY((fast ? launch_frame_fast : launch_frame)(ov.frame_threads, int(layout), morph, p.f16, fp, p.ntiles, flds, st));
     } else {
         HIP_TRY((fast ? launch_deform_fast : launch_deform)(threads, int(layout), morph, p.f16, dp, p.ntiles, lds, st));
-    }
-    if (m->side_stream && dp.morphed) {          // a later MMDX_MORPH_AHEAD pass into this buffer must wait for this reader
-        HIP_TRY(hipEventRecord(m->ev_read[m->morph_cur], st));
-        m->ev_read_set[m->morph_cur] = true;
     }
     if (pev) {
         HIP_TRY(hipEventRecord(pev[1], st));

@@ -85,21 +85,14 @@ struct mmdx_model_s {
         ell, entries, slot_top, chain_off, chain_rate;
     // per-call scratch (grown on demand, reused)
     mmdx::DevBuf pal, rates, wslot, morphed, out_a, out_b;
-    bool morphed_valid = false;     // the current position buffer holds the result of a shared morph pass (MMDX_MORPH_UNCHANGED)
-    // MMDX_MORPH_AHEAD: two position buffers (morphed, morphed_alt), a side stream for the morph pass, and per buffer the event
-    // "the last deform kernel that reads it has been queued" -- the next pass into that buffer waits for it
-    mmdx::DevBuf morphed_alt;
-    uint32_t morph_cur = 0;         // 0: `morphed` is the current buffer, 1: `morphed_alt`
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_morph_done = nullptr, ev_read[2] = {nullptr, nullptr};
-    bool ev_read_set[2] = {false, false};
+    bool morphed_valid = false;     // `morphed` holds the result of a shared morph pass (MMDX_MORPH_UNCHANGED)
     bool capturing = false;         // between mmdx_graph_begin and mmdx_graph_end: the stream records
     std::thread::id capture_thread; // ... begun on this thread (thread-local capture mode: it must end there too)
     mmdx::GraphPin pin;                   // graphs that hold addresses of this model's scratch buffers
     std::vector<mmdx::GraphPin *> rec_pins;   // handles that took part in the recording in progress (incl. this model)
     bool rec_poisoned = false;          // one of them was destroyed before mmdx_graph_end: the recording cannot become a graph
     mmdx_model_s() {
-        for (mmdx::DevBuf *b : {&pal, &rates, &wslot, &morphed, &morphed_alt, &out_a, &out_b}) b->pin = &pin;
+        for (mmdx::DevBuf *b : {&pal, &rates, &wslot, &morphed, &out_a, &out_b}) b->pin = &pin;
     }
     // page-locked bounce buffer for small outputs bound for pageable host memory (see mmdx_deform_batched)
     void *bounce = nullptr, *bounce_dev = nullptr;  // host address, device-side address

@@ -254,49 +254,3 @@ def _try(f):
         return f()
     except Exception as e:      # noqa: BLE001 -- handed to the asserting thread
         return e
-
-
-@gpu
-def test_morph_ahead_side_stream_pass(oracle, hip_lib):
-    """MMDX_MORPH_AHEAD: the shared morph pass of step k+1 runs on the handle's side stream into the other position buffer while
-    the model's stream still executes step k.  24 steps queued back to back without a host sync, every step with its OWN rates
-    and its OWN output arrays, flags cycling through ahead / plain / ahead / unchanged: every step's result is the oracle's."""
-    m = synth.make_model(6000, 50, 12, 500, seed=123)
-    ni, steps = 24, 24
-    pals = synth.make_palettes(m, np.arange(ni) * 3)
-    rates = synth.morph_weights(m.nm, np.arange(steps) * 11 + 2)
-    skin = oracle.normalize(m)
-    base = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
-    with DeformModel(m) as dm:
-        d_pal = DeviceBuffer.from_numpy(pals)
-        d_w = [DeviceBuffer.from_numpy(rates[k]) for k in range(steps)]
-        sa, sb = dm.out_sizes(api.OUT_SOA, ni)
-        outs = [(DeviceBuffer(sa), DeviceBuffer(sb)) for _ in range(steps)]
-        for a, b in outs:
-            a.memset(0xFF); b.memset(0xFF)
-        used = []
-        for k in range(steps):
-            mode = ("ahead", "plain", "ahead", "unchanged")[k % 4] if k else "ahead"
-            extra = {"ahead": api.MORPH_AHEAD, "plain": 0, "unchanged": api.MORPH_UNCHANGED}[mode]
-            dm.deform_batched_raw(ni, d_w[k].ptr if mode != "unchanged" else None, d_pal.ptr, outs[k][0].ptr, outs[k][1].ptr,
-                                  api.OUT_SOA, base | extra)
-            used.append(k if mode != "unchanged" else used[-1])          # the rates that step's positions come from
-        dm.sync()
-        for k in range(steps):
-            vimg = oracle.morph(m, rates[used[k]])
-            pos, nrm = outs[k][0].download((ni, m.nv, 3), np.float32), outs[k][1].download((ni, m.nv, 3), np.float32)
-            for i in (0, 7, ni - 1):
-                ep, en = oracle.skin(m, pals[i], vimg, skin)
-                gu.assert_bits_equal(pos[i], ep, f"step {k} inst {i} pos")
-                gu.assert_bits_equal(nrm[i], en, f"step {k} inst {i} nrm")
-        # a single frame and a per-instance-morph call in between leave the buffers' bookkeeping intact
-        p1, n1 = dm.deform(rates[3], pals[2])
-        ep, en = oracle.skin(m, pals[2], oracle.morph(m, rates[3]), skin)
-        gu.assert_bits_equal(p1, ep, "frame pos")
-        dm.deform_batched_raw(ni, None, d_pal.ptr, outs[0][0].ptr, outs[0][1].ptr, api.OUT_SOA, base | api.MORPH_UNCHANGED)
-        dm.sync()
-        vimg = oracle.morph(m, rates[used[-1]])
-        ep, en = oracle.skin(m, pals[5], vimg, skin)
-        gu.assert_bits_equal(outs[0][0].download((ni, m.nv, 3), np.float32)[5], ep, "unchanged after a frame: pos")
-        for b in [d_pal] + d_w + [x for ab in outs for x in ab]:
-            b.free()
