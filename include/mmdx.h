@@ -228,7 +228,11 @@ MMDX_API mmdx_status mmdx_model_set_stream(mmdx_model_t model, void *hip_stream)
  * (the model, and skeletons / motions called with it).  While the graph is alive those handles are pinned: a later call
  * on them that would have to GROW such a buffer fails with MMDX_ERR_INVALID_ARGUMENT instead of moving it (size the
  * buffers with an un-recorded call of the largest shape first); destroying a pinned handle is allowed and invalidates
- * the graph -- mmdx_graph_launch then fails, it never replays into freed memory. */
+ * the graph -- mmdx_graph_launch then fails, it never replays into freed memory.  A skeleton or motion destroyed WHILE
+ * a recording that used it is in progress poisons that recording (mmdx_graph_end reports it and returns no graph; its
+ * device blocks are freed at mmdx_graph_end, the runtime refuses frees on a recording thread); a model destroyed in
+ * the middle of its own recording ends the recording.  Recorded calls come from the thread that called
+ * mmdx_graph_begin. */
 typedef struct mmdx_graph_s *mmdx_graph_t;
 MMDX_API mmdx_status mmdx_graph_begin(mmdx_model_t model);
 MMDX_API mmdx_status mmdx_graph_end(mmdx_model_t model, mmdx_graph_t *out_graph);
