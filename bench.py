@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--plain-alloc", action="store_true", help="plain hipMalloc for the output arrays")
-    ap.add_argument("--shop-alloc", type=int, default=64, metavar="TRIES",
+    ap.add_argument("--shop-alloc", type=int, default=128, metavar="TRIES",
                     help="let mmdx_crowd_output_alloc try up to TRIES placements of the output arrays (bounded: ~5 ms per try, "
                          "every rank on its own GPU; the same bound at every N, so that per-N values compare like with like)")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle batches before the warm-up")
