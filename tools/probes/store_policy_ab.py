@@ -45,9 +45,31 @@ def use(l):
 
 
 def main():
+    # name=path.so[:VAR=VALUE[,VAR=VALUE...]]: launch-heuristic overrides (MMDX_THREADS, MMDX_GROUP, MMDX_LDS_TARGET ...) for
+    # THAT library only -- every build keeps its own copy of them, re-read by its mmdx_debug_reload_env; path "shipped" = the
+    # shipped build once more under other overrides
     specs = [a.split("=", 1) for a in sys.argv[1:]]
     base = api.lib()                                  # the shipped build: owns the shared buffers
-    libs = [("shipped", base)] + [(n, load(os.path.abspath(p))) for n, p in specs]
+    base.mmdx_debug_reload_env()
+    libs = [("shipped", base)]
+    n_copies = 0
+    for n, spec in specs:
+        path, _, envs = spec.partition(":")
+        if path == "shipped":                        # a second copy of the file = a second HIP module with its own overrides
+            import shutil
+            import tempfile
+            n_copies += 1
+            cp = os.path.join(tempfile.gettempdir(), "libmmdx_abcopy%d_%d.so" % (os.getpid(), n_copies))
+            shutil.copy(os.path.join(ROOT, "simple_mmd_renderer_amd", "libmmdx.so"), cp)
+            path = cp
+        l = load(os.path.abspath(path))
+        kv = [e.split("=", 1) for e in envs.split(",") if e]
+        for k, v in kv:
+            os.environ[k] = v
+        l.mmdx_debug_reload_env()
+        for k, _ in kv:
+            del os.environ[k]
+        libs.append((n, l))
     rounds, iters = int(os.environ.get("AB_ROUNDS", "9")), int(os.environ.get("AB_ITERS", "60"))
     wl = os.environ.get("AB_WORKLOAD", "c3")
     f16 = False
