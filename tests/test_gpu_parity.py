@@ -575,6 +575,50 @@ def test_config3_crowd_every_instance_vs_oracle(oracle):
         d_a.free(); d_b.free()
 
 
+def test_config4_every_ranks_shard_full_size_on_one_device(oracle):
+    """BASELINE config 4 (8192 instances sharded 1024 per GPU over 8 GPUs, no collective) has no node here: run what EVERY one
+    of its 8 ranks runs -- bench.py's set-up for world 8: shard_instances(8192, 8, r), crowd_frames of the GLOBAL instance ids,
+    1024 x 50k into placement-probed device arrays, shared rates -- one rank's shard after the other on the one device, and
+    compare a sample of every shard (its first, last and four inner instances, every vertex) bit for bit with the oracle posed
+    for the same global instance.  All 8 shards' outputs stay allocated together (9.8 GB), as they would on 8 devices."""
+    from simple_mmd_renderer_amd.crowd import crowd_frames, shard_instances
+    m = synth.make_config("config3_crowd")
+    world, per = 8, 1024
+    rates = synth.morph_weights(m.nm, 30)[0]
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    skin = oracle.normalize(m)
+    vimg = oracle.morph(m, rates)
+    row = m.nv * 12
+    keep = []
+    covered = 0
+    with DeformModel(m) as dm:
+        d_w = DeviceBuffer.from_numpy(rates)
+        for r in range(world):
+            lo, hi = shard_instances(per * world, world, r)
+            assert hi - lo == per and lo == covered
+            covered = hi
+            pals = synth.make_palettes(m, crowd_frames(lo, hi))
+            d_pal = DeviceBuffer.from_numpy(pals)
+            d_a, d_b, _pl = dm.alloc_outputs(api.OUT_SOA, per, 2)
+            d_a.memset(0xFF); d_b.memset(0xFF)
+            dm.deform_batched_raw(per, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA, flags, 1.0)
+            dm.sync()
+            keep.append((d_a, d_b, d_pal))
+            for j in (0, 1, 341, 682, per - 2, per - 1):
+                want = synth.make_palettes(m, crowd_frames(lo + j, lo + j + 1))[0]       # posed from the GLOBAL id alone
+                ep, en = oracle.skin(m, want, vimg, skin)
+                gu.assert_bits_equal(d_a.download((m.nv, 3), np.float32, offset=j * row), ep, f"rank {r} inst {lo + j} pos")
+                gu.assert_bits_equal(d_b.download((m.nv, 3), np.float32, offset=j * row), en, f"rank {r} inst {lo + j} nrm")
+        assert covered == per * world
+        # nothing a later shard did touched an earlier shard's arrays
+        d_a0, d_b0, d_pal0 = keep[0]
+        ep, en = oracle.skin(m, synth.make_palettes(m, crowd_frames(5, 6))[0], vimg, skin)
+        gu.assert_bits_equal(d_a0.download((m.nv, 3), np.float32, offset=5 * row), ep, "rank 0 inst 5 pos after all shards")
+        for d_a, d_b, d_pal in keep:
+            d_a.free(); d_b.free(); d_pal.free()
+        d_w.free()
+
+
 def test_config3_crowd_vertex32_full_size_bench_call_form(oracle):
     """BASELINE config 3 with the viewer's interleaved 32-byte vertex as output (Deform + UpdateDeformedVertices in one kernel,
     main.cpp:838-859), in EXACTLY the call form bench.py times as `config3_vertex32_output`: 1024 instances, shared rates of
