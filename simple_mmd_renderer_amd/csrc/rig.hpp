@@ -90,7 +90,7 @@ struct RoundRec {
 };
 constexpr uint32_t kSolveSlots = 16;            // events of one instance in flight
 constexpr uint32_t kSolveInstances = 16;        // instances per workgroup (kSolveSlots x kSolveInstances threads)
-constexpr size_t kSolveLdsBudget = 96 * 1024;   // LDS windows of one workgroup
+constexpr size_t kSolveLdsBudget = 72 * 1024;   // LDS windows of one workgroup
 
 struct SkeletonPlan {
     uint32_t nb = 0, n_pre = 0, n_post = 0, max_chain = 0;

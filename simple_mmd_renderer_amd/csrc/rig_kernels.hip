@@ -730,8 +730,12 @@ __global__ __launch_bounds__(kBoneMorphThreads) void bone_morph_kernel(const Bon
 // UpdateBoneTransform on the state the serial sequence would have shown it: same arithmetic, same result.
 // NESTED: the rig has an IK bone among some chain's links / targets (rig.cpp): the variant with the nested-solve call
 // sites (a stack, all 256 VGPRs); rigs without -- nearly all -- run the variant that has none.
-template <bool NESTED>
-__global__ __launch_bounds__(kSolveInstances * kSolveSlots) void skeleton_ordered_kernel(const SerialParams p) {
+// DENSE: the register allocation held to 256 VGPRs (the plain variant takes 292: one workgroup per CU) so that, with the
+// 72 KB LDS budget of the windows (rig.hpp), TWO workgroups share a CU.  A lone wave per SIMD is all a crowd of up to
+// 16 x (number of CUs) instances can use, and there the plain variant is 5 % faster (37 spilled registers); beyond that the
+// second wave per SIMD is worth 1.5 x the palettes per second (16 384 instances: 7.6 instead of 11.2 ms).  Chosen per launch.
+template <bool NESTED, bool DENSE>
+__global__ __launch_bounds__(kSolveInstances * kSolveSlots, DENSE ? 2 : 1) void skeleton_ordered_kernel(const SerialParams p) {
     const uint32_t slot = threadIdx.x / kSolveInstances;
     const uint32_t inst = blockIdx.x * kSolveInstances + threadIdx.x % kSolveInstances;
     const bool live = inst < p.ni;       // dead lanes skip the work but reach every barrier
@@ -949,14 +953,25 @@ hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream) {
     if (p.ni == 0 || p.nb == 0) return hipSuccess;
     const size_t lds = (size_t(window_floats(p.fast_slots)) * p.windows * kSolveInstances +
                         size_t(p.windows) * kMaxFastLinks * kLinkConstFloats) * sizeof(float);
-    auto kernel = p.nested ? skeleton_ordered_kernel<true> : skeleton_ordered_kernel<false>;
+    const uint32_t wgs = (p.ni + kSolveInstances - 1) / kSolveInstances;
+    static const int dense_env = env_int("MMDX_SOLVE_DENSE", -1);             // A/B: 0 never, 1 whenever it fits
+    bool dense = !p.nested && 2 * (lds + 1024) <= 160 * 1024;
+    if (dense && dense_env != 1) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        dense = dense_env != 0 && wgs > uint32_t(cus);
+    }
+    auto kernel = p.nested ? skeleton_ordered_kernel<true, false>
+                           : (dense ? skeleton_ordered_kernel<false, true> : skeleton_ordered_kernel<false, false>);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3((p.ni + kSolveInstances - 1) / kSolveInstances),
-                       dim3(kSolveInstances * kSolveSlots), lds, stream, p);
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(kSolveInstances * kSolveSlots), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 #include "rig.hpp"
 
 namespace mmdx {
+int env_int(const char *name, int dflt);   // api.cpp
 
 hipError_t launch_bone_track_eval(const BoneTrackParams &p, hipStream_t stream);
 hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream);

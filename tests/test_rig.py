@@ -523,6 +523,27 @@ def test_gpu_bone_morphs_vs_oracle(oracle, nb, seed, n_ik, n_app):
 
 
 @pytest.mark.gpu
+def test_gpu_ik_skeleton_crowd_beyond_one_workgroup_per_cu(oracle):
+    """More instances than 16 x (number of CUs): the ordered solver switches to its two-workgroups-per-CU variant (256 VGPRs,
+    spills; rig_kernels.hip launch_skeleton_ordered).  4 200 instances of a 44-bone rig with 3 IK chains and 4 append bones,
+    every 7th instance plus both ends against the oracle; the same poses through the small-crowd variant (the first 70
+    instances alone) must give the same bits."""
+    nb, seed = 44, 1
+    rest, parent, level, flags, ap, ar, ik = synth.make_ik_rig(nb, seed, n_ik=3, n_append=4)
+    ni = 4200
+    poses = np.tile(random_poses(300, nb, 977), (ni // 300, 1, 1))
+    rng = np.random.RandomState(5)
+    poses[..., 0:3] += rng.uniform(-0.2, 0.2, (ni, nb, 3)).astype(np.float32)     # every instance its own pose
+    sk = vmd.Skeleton(rest, parent, level, flags, ap, ar, ik)
+    got = sk.solve(poses)
+    for i in sorted(set(range(0, ni, 7)) | {1, ni - 2, ni - 1}):
+        want = oracle.bone_solve_full(rest, parent, poses[i], level, flags, ap, ar, ik)
+        gu.assert_bits_equal_or_both_nan(got[i], want, f"palette of instance {i}")
+    small = sk.solve(poses[:70])
+    assert np.array_equal(np.nan_to_num(small).view(np.uint32), np.nan_to_num(got[:70]).view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_gpu_full_size_crowd_rig(oracle):
     """BASELINE config-3 dimensions for the palette producer: 1024 instances x 300 bones, a 6000-key motion with
     ~16k distinct curve tables, every instance at its own frame.  Poses of 48 sampled instances and ALL 1024
