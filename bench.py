@@ -247,6 +247,9 @@ def main():
     skin_avg = skin_total / ncalls
     morph_avg = morph_total / ncalls
 
+    # cached non-temporal stores into arrays the placement probe found fast, write-through stores otherwise (mmdx.h,
+    # MMDX_OUT_STORES_*): what the library chose for these arrays
+    placement = dict(placement, store_policy=dm.last_store_policy())
     total_vertices = float(ni) * world * model.nv * args.steps
     value = total_vertices / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -329,7 +332,7 @@ def main():
             timed_batch(plain_step, 20)
             pl_ms = timed_batch(plain_step, args.steps)
             pl = {"ms_per_step": pl_ms, "vertices_per_s": ni * model.nv / (pl_ms * 1e-3),
-                  "step_frac": step_bytes / (pl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                  "step_frac": step_bytes / (pl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "store_policy": dm.last_store_policy()}
             if layout == api.OUT_SOA and model.nv % 4 == 0:
                 api.check(api.lib().mmdx_bench_store_pattern(p_a.ptr, p_b.ptr, model.nv, ni, 10, C.byref(ms)))
                 pl["store_pattern_GBs"] = ni * model.nv * 24 / (ms.value * 1e-3) / 1e9

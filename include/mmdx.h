@@ -146,11 +146,20 @@ enum {
     MMDX_OUT_ON_DEVICE = 1u << 2,     /* out_a/out_b are device pointers (else host; D2H + sync)   */
     MMDX_WEIGHTS_SHARED = 1u << 3,    /* one morph_weights[NM] for all instances (crowd with shared
                                          facial state): the morph pass runs once per call          */
-    MMDX_MORPH_UNCHANGED = 1u << 4    /* with MMDX_WEIGHTS_SHARED and NI > 1: the morph weights are those of the
+    MMDX_MORPH_UNCHANGED = 1u << 4,   /* with MMDX_WEIGHTS_SHARED and NI > 1: the morph weights are those of the
                                          previous such call on this model (a crowd whose facial state
                                          changes less often than its poses): the morphed positions of that
                                          call are reused and the morph pass is skipped; morph_weights is
                                          not read.  An error without such an earlier call.            */
+    /* Hints for crowds whose outputs stream through the caches (device arrays of >= 512 MB per call): how the kernel
+       writes them.  By default the library decides: arrays from mmdx_crowd_output_alloc by what its probe measured
+       (fast store mode: cached non-temporal stores; otherwise write-through stores, ~5 % faster there, 2 % slower in
+       the fast mode), arrays it knows nothing about write-through (six plain allocations in seven are not in the fast
+       mode).  A caller who has measured its own arrays (mmdx_bench_store_pattern against mmdx_bench_fill,
+       mmdx_bench.h) can say so.  Results are identical either way; kernels without a write-through flavour ignore
+       the hint; the two exclude each other.                                                          */
+    MMDX_OUT_STORES_WRITE_THROUGH = 1u << 5,
+    MMDX_OUT_STORES_CACHED = 1u << 6
 };
 
 typedef struct mmdx_deform_args {

@@ -32,6 +32,9 @@ MMDX_API mmdx_status mmdx_profile_collect(mmdx_model_t model, uint32_t *n_calls,
 /* The launch-shape overrides for A/B runs (environment variables MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET,
  * MMDX_INTERLEAVE; tools/ab.py) are read once per process; this re-reads them.  Not for product use. */
 MMDX_API void mmdx_debug_reload_env(void);
+/* Which store flavour the model's last mmdx_deform_batched call asked of its kernel: 0 = cached non-temporal stores, 1 =
+ * write-through (mmdx.h, MMDX_OUT_STORES_*; kernels without a write-through flavour run their usual stores either way). */
+MMDX_API mmdx_status mmdx_debug_last_store_policy(mmdx_model_t model, int32_t *write_through);
 /* Device-to-device streaming copy / fill timed with HIP events: the practical HBM ceiling printed
  * next to the roofline.  bytes_moved = 2*bytes for copy, bytes for fill. */
 MMDX_API mmdx_status mmdx_bench_copy(void *dst_device, const void *src_device, size_t bytes,

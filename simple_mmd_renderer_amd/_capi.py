@@ -19,6 +19,7 @@ ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5:
 CREATE_NORMALIZE, CREATE_HOST_ONLY, CREATE_F16_POSITIONS, CREATE_FAST_MATH, CREATE_TILE_ORDER = 1, 2, 4, 8, 16
 OUT_SOA, OUT_VERTEX32, OUT_SOA_POS16 = 0, 1, 2
 PALETTE_ON_DEVICE, WEIGHTS_ON_DEVICE, OUT_ON_DEVICE, WEIGHTS_SHARED, MORPH_UNCHANGED = 1, 2, 4, 8, 16
+OUT_STORES_WRITE_THROUGH, OUT_STORES_CACHED = 32, 64
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -92,6 +93,7 @@ SIGNATURES = {
     "mmdx_device_memset": (C.c_int32, [C.c_void_p, C.c_int, C.c_size_t]),
     "mmdx_device_synchronize": (C.c_int32, []),
     "mmdx_debug_reload_env": (None, []),
+    "mmdx_debug_last_store_policy": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mmdx_bench_copy": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
     "mmdx_bench_fill": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
     "mmdx_bench_store_pattern": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, _f32p]),

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <new>
 #include <string>
 #include <thread>
@@ -62,6 +63,27 @@ struct mmdx_graph_s {
 
 namespace {
 std::mutex g_graph_mu;          // graph <-> handle links (rare operations: record, destroy)
+
+// What mmdx_crowd_output_alloc learned about the arrays it handed out: first array -> "stores at the fast rate".  The crowd call
+// picks the store flavour of its copy-out from it (write_through_for); entries leave with mmdx_device_free.
+std::mutex g_place_mu;
+std::unordered_map<const void *, bool> g_place_fast;
+
+// Store flavour of a crowd launch (kernels.hip CopyFast): `nt` where the arrays are known to sit in the fast store mode,
+// `sc1 nt` (write-through) where they are known not to -- and where nothing is known, because six plain allocations in seven are
+// not (expected cost of the wrong guess: 2 % on a fast pair against 4.6-5 % on the others).  Only outputs large enough to stream
+// through the caches (>= 512 MB) are considered, and only the kernels that have the flavour (kernels.hip pick()).
+// Caller's hints first, then MMDX_STORE_WT=0 / 1 (A/B), then the registry.
+bool write_through_for(const void *out_a, size_t out_bytes, uint32_t flags) {
+    if (flags & MMDX_OUT_STORES_WRITE_THROUGH) return true;
+    if (flags & MMDX_OUT_STORES_CACHED) return false;
+    static const int env = env_int("MMDX_STORE_WT", -1);
+    if (env == 0 || env == 1) return env == 1;
+    if (out_bytes < (size_t(512) << 20)) return false;
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    const auto it = g_place_fast.find(out_a);
+    return it == g_place_fast.end() ? true : !it->second;
+}
 }
 void mmdx::graph_note_handle(mmdx_model_s *model, GraphPin *pin) {
     if (!model || !model->capturing || !pin) return;
@@ -462,8 +484,11 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     const Plan &p = m->plan;
     const uint32_t ni = a->n_instances, layout = a->out_layout;
     if (ni == 0) return fail(MMDX_ERR_INVALID_ARGUMENT, "n_instances must be >= 1");
-    if (a->flags & ~uint32_t(MMDX_PALETTE_ON_DEVICE | MMDX_WEIGHTS_ON_DEVICE | MMDX_OUT_ON_DEVICE | MMDX_WEIGHTS_SHARED | MMDX_MORPH_UNCHANGED))
+    if (a->flags & ~uint32_t(MMDX_PALETTE_ON_DEVICE | MMDX_WEIGHTS_ON_DEVICE | MMDX_OUT_ON_DEVICE | MMDX_WEIGHTS_SHARED | MMDX_MORPH_UNCHANGED |
+                             MMDX_OUT_STORES_WRITE_THROUGH | MMDX_OUT_STORES_CACHED))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown bits in mmdx_deform_args.flags");
+    if ((a->flags & MMDX_OUT_STORES_WRITE_THROUGH) && (a->flags & MMDX_OUT_STORES_CACHED))
+        return fail(MMDX_ERR_INVALID_ARGUMENT, "MMDX_OUT_STORES_WRITE_THROUGH and MMDX_OUT_STORES_CACHED exclude each other");
     if (layout > MMDX_OUT_SOA_POS16) return fail(MMDX_ERR_INVALID_ARGUMENT, "unknown out_layout");
     if (p.f16 != (layout == MMDX_OUT_SOA_POS16))
         return fail(MMDX_ERR_UNSUPPORTED, "MMDX_OUT_SOA_POS16 goes with MMDX_CREATE_F16_POSITIONS models "
@@ -641,6 +666,9 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         }
     }
     dp.out_aligned = ((reinterpret_cast<uintptr_t>(dp.out_a) | reinterpret_cast<uintptr_t>(dp.out_b)) & 15) == 0;
+    // outputs in device memory only: stores into mapped host memory cross PCIe whatever their cache bits say
+    dp.write_through = out_dev && write_through_for(dp.out_a, bytes_a + bytes_b, a->flags) ? 1u : 0u;
+    m->last_write_through = dp.write_through != 0;
 
     // ---- workgroup shape ------------------------------------------------------------------------------
     // 256 threads / two vertex slots per lane everywhere except the per-instance-morph path: there one slot
@@ -946,7 +974,13 @@ mmdx_status mmdx_host_free(void *ptr) {
 }
 
 mmdx_status mmdx_device_free(void *ptr) {
-    if (ptr) HIP_TRY(hipFree(ptr));
+    if (ptr) {
+        {
+            std::lock_guard<std::mutex> lk(g_place_mu);
+            g_place_fast.erase(ptr);
+        }
+        HIP_TRY(hipFree(ptr));
+    }
     return MMDX_OK;
 }
 
@@ -1069,6 +1103,10 @@ mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_
     HIP_TRY(hipDeviceSynchronize());
     *out_a = best.a;
     *out_b = best.b;
+    if (can_probe && fill_gbs > 0.f) {
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        g_place_fast[best.a] = best.gbs >= 0.92f * fill_gbs;
+    }
     if (info) {
         info->tries = tries;
         info->probed = can_probe ? 1u : 0u;

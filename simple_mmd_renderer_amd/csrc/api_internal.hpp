@@ -91,6 +91,7 @@ struct mmdx_model_s {
     mmdx::GraphPin pin;                   // graphs that hold addresses of this model's scratch buffers
     std::vector<mmdx::GraphPin *> rec_pins;   // handles that took part in the recording in progress (incl. this model)
     bool rec_poisoned = false;          // one of them was destroyed before mmdx_graph_end: the recording cannot become a graph
+    bool last_write_through = false;          // store flavour of the last crowd launch (mmdx_debug_last_store_policy)
     mmdx_model_s() {
         for (mmdx::DevBuf *b : {&pal, &rates, &wslot, &morphed, &out_a, &out_b}) b->pin = &pin;
     }

@@ -77,6 +77,12 @@ mmdx_status mmdx_profile_collect(mmdx_model_t m, uint32_t *n_calls, float *skin_
 
 void mmdx_debug_reload_env(void) { launch_overrides() = read_launch_overrides(); }
 
+mmdx_status mmdx_debug_last_store_policy(mmdx_model_t model, int32_t *write_through) {
+    if (!model || !write_through) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *write_through = model->last_write_through ? 1 : 0;
+    return MMDX_OK;
+}
+
 static mmdx_status bench_stream_op(void *dst, const void *src, size_t bytes, int32_t iters, float *avg_ms) {
     if (!dst || !avg_ms || iters <= 0 || bytes < 16) return fail(MMDX_ERR_INVALID_ARGUMENT, "bad argument");
     hipEvent_t e0, e1;

@@ -210,7 +210,13 @@ __device__ __forceinline__ void copy_out2(const unsigned char *imgA, TA *outA, s
 // when NV % 4 == 0): all LDS reads are issued first, then all stores -- one LDS round trip per
 // instance instead of one per chunk, no per-chunk branching.  CA / CB = 16-byte chunks of image A / B;
 // image B sits `gapB` bytes after image A in LDS.
-template <int THREADS, int CA, int CB, int I>
+// WT (write-through): the 16-byte stores carry `sc1 nt` instead of `nt` -- the line is written through to memory and dropped from
+// the XCD's L2.  On output arrays whose physical backing is in the slow store mode (six plain allocations in
+// seven) the SoA crowd kernel runs 4.6-5.0 % faster with it (251.6 -> 240.0 us), in the fast mode 2 % slower (207.0 -> 211.4):
+// profiles/r03/store_policy_buffer_builtin_ab*.txt -- so the host picks per launch (api.cpp).  Issued through the buffer-store
+// builtin: the compiler sees the instruction and keeps its data hazards (the inline-asm flavours of MMDX_STORE_POLICY did not,
+// and corrupted results); descriptor = this instance's piece of the array (wave-uniform), lane offset in bytes.
+template <int THREADS, int CA, int CB, int I, bool WT = false>
 struct CopyFast {
     // step I of ceil((CA+CB)/THREADS): load chunk q = tid + I*THREADS, recurse (so every LDS read is
     // issued before the first store), then store it.  Scalars only -- an indexed float4 array here
@@ -226,18 +232,31 @@ struct CopyFast {
             if (full || q < TOTAL)
                 v = *reinterpret_cast<const float4 *>(img + (inA ? 0u : gapB - uint32_t(CA) * 16u) +
                                                       size_t(q) * 16);
-            CopyFast<THREADS, CA, CB, I + 1>::run(img, gapB, outA, outB, tid);
+            CopyFast<THREADS, CA, CB, I + 1, WT>::run(img, gapB, outA, outB, tid);
             if (full || q < TOTAL) {
-                float4 *dst = inA ? outA + q : outB + (q - CA);
-                store16(dst, v);
+                if constexpr (WT) {
+                    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+                    constexpr int kSc1Nt = 2 | 16;                      // cache-policy bits of the buffer intrinsics: nt, sc1
+                    const v4u d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                    if (inA) {
+                        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(outA, 0, uint32_t(CA) * 16u, 0x00027000);
+                        __builtin_amdgcn_raw_buffer_store_b128(d, r, uint32_t(q) * 16u, 0, kSc1Nt);
+                    } else {
+                        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(outB, 0, uint32_t(CB) * 16u, 0x00027000);
+                        __builtin_amdgcn_raw_buffer_store_b128(d, r, uint32_t(q - CA) * 16u, 0, kSc1Nt);
+                    }
+                } else {
+                    float4 *dst = inA ? outA + q : outB + (q - CA);
+                    store16(dst, v);
+                }
             }
         }
     }
 };
-template <int THREADS, int CA, int CB>
+template <int THREADS, int CA, int CB, bool WT = false>
 __device__ __forceinline__ void copy_out_fast(const unsigned char *img, uint32_t gapB, float4 *outA,
                                               float4 *outB, int tid) {
-    CopyFast<THREADS, CA, CB, 0>::run(img, gapB, outA, outB, tid);
+    CopyFast<THREADS, CA, CB, 0, WT>::run(img, gapB, outA, outB, tid);
 }
 
 struct Slot {
@@ -587,7 +606,7 @@ __device__ __forceinline__ M12 skin_matrix(const Slot &q, const float4 *P) {
 // One instance: skin the thread's slots with the palette at P (LDS), scatter the results to the LDS image `img`
 // (undoing the class sort), ONE workgroup barrier, then write the image out with coalesced 16-byte stores.
 // `inst` = the instance's index in the output arrays, cxy / cz = the (morphed) positions of the thread's slots.
-template <int THREADS, int LAYOUT, int VPT, bool TILE, bool ALL_FAST>
+template <int THREADS, int LAYOUT, int VPT, bool TILE, bool ALL_FAST, bool WT = false>
 __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot (&sl)[VPT], const float4 *P,
                                               unsigned char *img, uint32_t inst, uint32_t v0, uint32_t nvt,
                                               const v2f (&cxy)[VPT], const float (&cz)[VPT], int tid) {
@@ -655,7 +674,7 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
     if constexpr (LAYOUT == MMDX_OUT_SOA) {
         float *oa = reinterpret_cast<float *>(p.out_a), *ob = reinterpret_cast<float *>(p.out_b);
         if (fast)
-            copy_out_fast<THREADS, kTileVerts * 12 / 16, kTileVerts * 12 / 16>(
+            copy_out_fast<THREADS, kTileVerts * 12 / 16, kTileVerts * 12 / 16, WT>(
                 img, kSoaImgBytes, reinterpret_cast<float4 *>(oa + vbase * 3),
                 reinterpret_cast<float4 *>(ob + vbase * 3), tid);
         else
@@ -685,7 +704,7 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
 
 // ---- the deformation kernel ----------------------------------------------------------------------
 // THREADS = 512: one sorted slot per lane, 8 waves per workgroup; THREADS = 256: two slots per lane.
-template <int THREADS, int LAYOUT, int MORPH, bool F16, bool TILE>
+template <int THREADS, int LAYOUT, int MORPH, bool F16, bool TILE, bool WT = false>
 __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     constexpr int VPT = int(kTileVerts) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     constexpr bool kAllFast = decltype(all_fast_tag)::value;
     // the image is double buffered: the next instance writes the other one, so one barrier per instance is enough
     auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT]) {
-        skin_instance<THREADS, LAYOUT, VPT, TILE, kAllFast>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
+        skin_instance<THREADS, LAYOUT, VPT, TILE, kAllFast, WT>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
                                                            inst0 + g * istep, v0, nvt, cxy, cz, tid);
         buf ^= 1u;
     };
@@ -1098,8 +1117,13 @@ KernelFn pick_t(int layout, int morph, bool f16) {
     return nullptr;
 }
 
-// tile = outputs in the engine's vertex order (MMDX_CREATE_TILE_ORDER): the direct-store variants
-KernelFn pick(int threads, int layout, int morph, bool f16, bool tile) {
+// tile = outputs in the engine's vertex order (MMDX_CREATE_TILE_ORDER): the direct-store variants.
+// wt = write-through stores (CopyFast): instantiated where it was measured to pay -- the SoA f32 crowd kernels (256 threads, no
+// morphs or shared morphs, original vertex order); every other shape keeps its nt stores whatever the hint says.
+KernelFn pick(int threads, int layout, int morph, bool f16, bool tile, bool wt = false) {
+    if (wt && threads == 256 && layout == MMDX_OUT_SOA && !f16 && !tile && (morph == kMorphNone || morph == kMorphShared))
+        return morph == kMorphNone ? deform_kernel<256, MMDX_OUT_SOA, kMorphNone, false, false, true>
+                                   : deform_kernel<256, MMDX_OUT_SOA, kMorphShared, false, false, true>;
 #if MMDX_TILE >= 512
     if (threads != 256) return tile ? pick_t<512, true>(layout, morph, f16) : pick_t<512, false>(layout, morph, f16);
 #endif
@@ -1153,6 +1177,11 @@ hipError_t MMDX_K(prepare_kernels)() {
                                                    160 * 1024);
                 if (e != hipSuccess) return e;
             }
+    for (int morph : {int(kMorphNone), int(kMorphShared)}) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pick(256, MMDX_OUT_SOA, morph, false, false, true)),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     for (int threads = 128; threads <= 256; threads += 128)
       for (int f16 = 0; f16 < 2; ++f16)
         for (int layout = 0; layout < 3; ++layout)
@@ -1168,7 +1197,7 @@ hipError_t MMDX_K(prepare_kernels)() {
 
 hipError_t MMDX_K(launch_deform)(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream) {
-    KernelFn fn = pick(threads, layout, morph, f16, p.tile_order != 0);
+    KernelFn fn = pick(threads, layout, morph, f16, p.tile_order != 0, p.write_through != 0);
     if (!fn) return hipErrorInvalidValue;
     DeformParams q = p;
     q.ntiles = ntiles;

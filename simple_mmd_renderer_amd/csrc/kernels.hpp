@@ -62,6 +62,7 @@ struct DeformParams {
     uint32_t interleave;         // crowd modes: instance = g*ngroups + grp instead of grp*group + g
     uint32_t tile_order;         // MMDX_CREATE_TILE_ORDER: outputs in the engine's vertex order (tile-local class sort), stored straight
                                  // from registers -- no LDS image, no per-instance barrier
+    uint32_t write_through;      // host-side hint (launch_deform): the write-through flavour of the copy-out, where one exists
 };
 
 struct FlattenParams {

@@ -314,6 +314,12 @@ class DeformModel:
     def sync(self) -> None:
         api.check(api.lib().mmdx_sync(self.h))
 
+    def last_store_policy(self) -> str:
+        """Store flavour the last crowd call asked of its kernel: 'nt' (cached, non-temporal) or 'sc1 nt' (write-through)."""
+        wt = C.c_int32(0)
+        api.check(api.lib().mmdx_debug_last_store_policy(self.h, C.byref(wt)))
+        return "sc1 nt" if wt.value else "nt"
+
     def timer_start(self) -> None:
         api.check(api.lib().mmdx_timer_start(self.h))
 

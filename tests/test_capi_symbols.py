@@ -24,6 +24,7 @@ def test_boundary_header_carries_no_bench_or_debug_entry_points():
     assert not [s for s in syms if s.startswith(("mmdx_bench_", "mmdx_debug_", "mmdx_timer_", "mmdx_profile_"))]
     assert set(declared_symbols((BENCH_HEADER,))) == {
         "mmdx_timer_start", "mmdx_timer_stop", "mmdx_profile_enable", "mmdx_profile_collect", "mmdx_debug_reload_env",
+        "mmdx_debug_last_store_policy",
         "mmdx_bench_copy", "mmdx_bench_fill", "mmdx_bench_store_pattern"}
 
 

@@ -619,6 +619,63 @@ def test_config4_every_ranks_shard_full_size_on_one_device(oracle):
         d_w.free()
 
 
+def test_crowd_store_policy_hints_and_defaults(oracle):
+    """The store flavour of the crowd kernel's copy-out (mmdx.h MMDX_OUT_STORES_*): write-through (`sc1 nt`) or cached
+    non-temporal (`nt`) stores -- same results, bit for bit, whichever is chosen, and the default follows what the library knows
+    about the arrays: from mmdx_crowd_output_alloc by the probe's verdict, unknown arrays write-through, small crowds never."""
+    from simple_mmd_renderer_amd.crowd import crowd_frames
+    m = synth.make_config("config3_crowd")
+    ni = 1024
+    pals = synth.make_palettes(m, crowd_frames(0, ni))
+    rates = synth.morph_weights(m.nm, 30)[0]
+    base = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    skin = oracle.normalize(m)
+    vimg = oracle.morph(m, rates)
+    row = m.nv * 12
+    sample = sorted(set(range(0, ni, 128)) | {1, 17, ni - 1})
+    want = {i: oracle.skin(m, pals[i], vimg, skin) for i in sample}
+    with DeformModel(m) as dm:
+        d_w, d_pal = DeviceBuffer.from_numpy(rates), DeviceBuffer.from_numpy(pals)
+        d_a, d_b, pl = dm.alloc_outputs(api.OUT_SOA, ni, 4)                 # probed: the registry knows these arrays
+        p_a, p_b = DeviceBuffer(ni * row), DeviceBuffer(ni * row)           # plain: it does not
+
+        def run(a, b, flags, n=ni):
+            a.memset(0xFF); b.memset(0xFF)
+            dm.deform_batched_raw(n, d_w.ptr, d_pal.ptr, a.ptr, b.ptr, api.OUT_SOA, flags, 1.0)
+            dm.sync()
+            return dm.last_store_policy()
+
+        def check(a, b, what):
+            for i in sample:
+                gu.assert_bits_equal(a.download((m.nv, 3), np.float32, offset=i * row), want[i][0], f"{what}: inst {i} pos")
+                gu.assert_bits_equal(b.download((m.nv, 3), np.float32, offset=i * row), want[i][1], f"{what}: inst {i} nrm")
+
+        assert run(p_a, p_b, base | api.OUT_STORES_WRITE_THROUGH) == "sc1 nt"
+        check(p_a, p_b, "write-through hint")
+        assert run(p_a, p_b, base | api.OUT_STORES_CACHED) == "nt"
+        check(p_a, p_b, "cached hint")
+        assert run(p_a, p_b, base) == "sc1 nt"                               # nothing known about these arrays
+        check(p_a, p_b, "default, unknown arrays")
+        fast = pl["store_GBs"] >= 0.92 * pl["fill_GBs"]
+        assert run(d_a, d_b, base) == ("nt" if fast else "sc1 nt")          # the probe's verdict
+        check(d_a, d_b, "default, probed arrays")
+        assert run(d_a, d_b, base | api.MORPH_UNCHANGED | api.OUT_STORES_WRITE_THROUGH) == "sc1 nt"   # the no-morph-pass kernel too
+        check(d_a, d_b, "write-through, morph pass skipped")
+        assert run(p_a, p_b, base, n=64) == "nt"                             # 77 MB of output: stays cached
+        with pytest.raises(api.MmdxError):
+            dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, p_a.ptr, p_b.ptr, api.OUT_SOA,
+                                  base | api.OUT_STORES_WRITE_THROUGH | api.OUT_STORES_CACHED, 1.0)
+        # layouts / kernels without a write-through flavour take the hint and run their usual stores
+        v32 = DeviceBuffer(ni * m.nv * 32)
+        dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, v32.ptr, None, api.OUT_VERTEX32, base | api.OUT_STORES_WRITE_THROUGH, 0.1)
+        dm.sync()
+        for i in sample[:3]:
+            gu.assert_bits_equal(v32.download((m.nv, 8), np.float32, offset=i * m.nv * 32),
+                                 oracle.repack32(m, want[i][0], want[i][1], 0.1), f"v32 with the hint: inst {i}")
+        for b in (d_a, d_b, p_a, p_b, v32, d_w, d_pal):
+            b.free()
+
+
 def test_config3_crowd_vertex32_full_size_bench_call_form(oracle):
     """BASELINE config 3 with the viewer's interleaved 32-byte vertex as output (Deform + UpdateDeformedVertices in one kernel,
     main.cpp:838-859), in EXACTLY the call form bench.py times as `config3_vertex32_output`: 1024 instances, shared rates of

@@ -52,6 +52,7 @@ def main():
     base = api.lib()                                  # the shipped build: owns the shared buffers
     base.mmdx_debug_reload_env()
     libs = [("shipped", base)]
+    lib_flags = {"shipped": 0}
     n_copies = 0
     for n, spec in specs:
         path, _, envs = spec.partition(":")
@@ -64,6 +65,8 @@ def main():
             path = cp
         l = load(os.path.abspath(path))
         kv = [e.split("=", 1) for e in envs.split(",") if e]
+        lib_flags[n] = sum(int(v, 0) for k, v in kv if k == "FLAGS")     # FLAGS=32: extra mmdx_deform_args.flags for this entry
+        kv = [(k, v) for k, v in kv if k != "FLAGS"]
         for k, v in kv:
             os.environ[k] = v
         l.mmdx_debug_reload_env()
@@ -110,6 +113,7 @@ def main():
             placements.append(("plain hipMalloc" + rate, pa, pb))
 
     def burst(dm, l, n, a, b, extra=0):
+        extra |= lib_flags[[nm for nm, ll in libs if ll is l][0]] if sum(1 for _, ll in libs if ll is l) == 1 else 0
         with use(l):
             for _ in range(n):
                 dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, a.ptr, b.ptr if b else None, layout, flags | extra, scale)
