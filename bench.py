@@ -301,7 +301,7 @@ def main():
         if rank == 0:
             result["roofline"]["output_placement_per_rank"] = tries
     if rank == 0:
-        result["roofline"].update(pmc_traffic(layout == api.OUT_SOA, ni, model.nv))
+        result["roofline"].update(pmc_traffic(layout == api.OUT_SOA, ni, model.nv, placement.get("store_policy", "nt")))
         result["device"] = device_name(local_rank % ndev)
         # practical ceilings on this box (SURVEY.md section 8d asks for them next to the spec peak)
         nb_ceiling = 1 << 30
@@ -407,7 +407,7 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(is_default_layout: bool, ni: int, nv: int):
+def pmc_traffic(is_default_layout: bool, ni: int, nv: int, store_policy: str = "nt"):
     """HBM bytes per launch of the deform kernel from the committed rocprofv3 PMC passes
     (profiles/rNN/config3_pmc_hbm_traffic.csv: FETCH_SIZE and WRITE_SIZE collected in separate
     passes).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts wide streaming reads at
@@ -431,16 +431,18 @@ def pmc_traffic(is_default_layout: bool, ni: int, nv: int):
     if diff or any(os.environ.get(k) for k in ("MMDX_GROUP", "MMDX_THREADS", "MMDX_INTERLEAVE", "MMDX_LDS_TARGET")):
         return {"traffic": None, "traffic_withheld": f"{src} was collected for another build / workload: {diff}"}
     fetch = write = None
+    # the deform kernel exists in two store flavours (last template argument: write-through); the row of the one THIS run launched
+    flavour = ", true>" if store_policy == "sc1 nt" else ", false>"
     for row in csv.DictReader(open(files[-1])):
-        if "deform_kernel" in row["kernel"]:
+        if "deform_kernel" in row["kernel"] and flavour in row["kernel"]:
             if row["counter"] == "FETCH_SIZE":
                 fetch = float(row["mean_KB"]) * 1024
             elif row["counter"] == "WRITE_SIZE":
                 write = float(row["mean_KB"]) * 1024
     if fetch is None or write is None:
-        return {"traffic": None}
+        return {"traffic": None, "traffic_withheld": f"{src} holds no launch of the {store_policy}-store flavour this run used"}
     return {"traffic": write + 2 * fetch, "traffic_detail": {
-        "write_bytes": write, "fetch_bytes_reported": fetch, "fetch_correction": 2.0, "source": src}}
+        "write_bytes": write, "fetch_bytes_reported": fetch, "fetch_correction": 2.0, "source": src, "store_flavour": store_policy}}
 
 
 def fused_pmc_traffic(out):

@@ -31,22 +31,31 @@ def main(src, dst):
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "config3_bench_under_rocprof.json"))
     line = json.load(open(os.path.join(src, "bench_under_rocprof.json")))
     segs = line["roofline"]["trace_segments"]          # deform-kernel launches at the end of the run, oldest first
-    per = collections.OrderedDict()
+    # every launch of the deform kernel, whichever store flavour it was instantiated with (cached / write-through: the bench's
+    # plain-allocation leg usually runs the other one), in launch order; the morph pass separately
+    deform, morph = [], []
     with open(os.path.join(src, "kt", "kt_kernel_trace.csv"), newline="") as f:
         for r in csv.DictReader(f):
-            per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            t = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"])
+            if "deform_kernel" in t[2]:
+                deform.append(t)
+            elif "morph_apply" in t[2]:
+                morph.append(t)
+    deform.sort()
     with open(os.path.join(dst, "config3_kernel_trace_timed_region.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "dispatches_in_trace", "segment", "n", "avg_ns", "min_ns", "max_ns", "avg_ns_all"])
-        for k, v in per.items():
-            if "deform_kernel" in k:
-                pos = len(v) - sum(n for _, n in segs)
-                for name, n in segs:
-                    t = v[pos:pos + n]
-                    pos += n
-                    w.writerow([k, len(v), name, len(t), sum(t) / len(t), min(t), max(t), sum(v) / len(v)])
-            elif "morph_apply" in k:
-                w.writerow([k, len(v), "all", len(v), sum(v) / len(v), min(v), max(v), sum(v) / len(v)])
+        pos = len(deform) - sum(n for _, n in segs)
+        all_avg = sum(d for _, d, _ in deform) / len(deform)
+        for name, n in segs:
+            part = deform[pos:pos + n]
+            pos += n
+            t = [d for _, d, _ in part]
+            kernels = sorted({k for _, _, k in part})
+            w.writerow([" | ".join(kernels), len(deform), name, len(t), sum(t) / len(t), min(t), max(t), all_avg])
+        if morph:
+            v = [d for _, d, _ in morph]
+            w.writerow([morph[0][2], len(v), "all", len(v), sum(v) / len(v), min(v), max(v), sum(v) / len(v)])
     # provenance of the PMC figures bench.py quotes as roofline.traffic: the build and workload they were collected for
     with open(os.path.join(dst, "config3_pmc_hbm_traffic.meta.json"), "w") as f:
         json.dump({"kernel_source_sha": line["roofline"]["kernel_source_sha"],
