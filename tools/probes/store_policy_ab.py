@@ -102,7 +102,7 @@ def main():
         tries = int(os.environ.get("AB_TRIES", "48"))
         a, b, info = dms[0].alloc_outputs(layout, ni, tries)
         placements.append(("shopped(%d tries, %.0f of %.0f GB/s)" % (info["tries"], info["store_GBs"], info["fill_GBs"]), a, b))
-        if os.environ.get("AB_PLAIN", "1") == "1":
+        for _plain in range(int(os.environ.get("AB_PLAIN_N", "1")) if os.environ.get("AB_PLAIN", "1") == "1" else 0):   # AB_PLAIN_N pairs, all kept: fresh memory each
             sa, sb = dms[0].out_sizes(layout, ni)
             pa, pb = DeviceBuffer(sa), (DeviceBuffer(sb) if sb else None)
             rate = ""
