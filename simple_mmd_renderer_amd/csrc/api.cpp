@@ -693,6 +693,12 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         uint32_t g = target > fixed ? uint32_t((target - fixed) / per) : 0u;
         g = std::min(g, (morph == kMorphFused4 || dp.tile_order) ? 16u : 32u);   // tile order: 16 219 us, 32 229 us, 8 244 us
         if (g >= 8) g &= ~3u;   // measured: 16 beats 17 (even split of 1024 instances, aligned strides)
+        // write-through stores go to arrays that are not in the fast store mode; there 8 instances per workgroup (four workgroups
+        // per CU, half the open output streams each) beat 16 by 3-8 % -- 218-224 vs 225-241 us on four such pairs, while on a fast
+        // pair 16 wins (204 vs 211): profiles/r03/shape_sweep_write_through*.txt
+        if (dp.write_through && threads == 256 && layout == MMDX_OUT_SOA && !p.f16 && !dp.tile_order &&
+            (morph == kMorphNone || morph == kMorphShared))
+            g = std::min(g, 8u);
         g = std::max(g / gmin * gmin, gmin);
         const uint32_t ni_up = (ni + gmin - 1) / gmin * gmin;
         g = std::min(g, ni_up);
