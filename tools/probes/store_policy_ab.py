@@ -77,7 +77,7 @@ def main():
     wl = os.environ.get("AB_WORKLOAD", "c3")
     f16 = False
     if wl in ("c3", "v32", "c3p"):
-        model, ni = synth.make_config("config3_crowd"), 1024
+        model, ni = synth.make_config("config3_crowd"), int(os.environ.get("AB_NI", "1024"))
         pals = synth.make_palettes(model, (np.arange(ni) * 3) % 1801)
         rates = synth.morph_weights(model.nm, 30)[0] if wl != "c3p" else synth.morph_weights(model.nm, np.arange(ni) % 600)
         layout = api.OUT_VERTEX32 if wl == "v32" else api.OUT_SOA
