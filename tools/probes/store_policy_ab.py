@@ -82,6 +82,11 @@ def main():
         rates = synth.morph_weights(model.nm, 30)[0] if wl != "c3p" else synth.morph_weights(model.nm, np.arange(ni) % 600)
         layout = api.OUT_VERTEX32 if wl == "v32" else api.OUT_SOA
         shared = wl != "c3p"
+    elif wl == "c5s":                                  # the 256k-vertex f16 model as a crowd with shared morphs (two arrays: 6 + 12 B)
+        model, ni = synth.make_config("config5_256k"), int(os.environ.get("AB_NI", "256"))
+        pals = synth.make_palettes(model, np.arange(ni))
+        rates = synth.morph_weights(model.nm, 30)[0]
+        f16, layout, shared = True, api.OUT_SOA_POS16, True
     else:
         cfg, ni = ("config5_256k", 64) if wl == "c5x64" else ("config2_50k", 64)
         model = synth.make_config(cfg)
