@@ -287,7 +287,9 @@ MMDX_API mmdx_status mmdx_device_synchronize(void);
  * against a linear fill, and retries up to `max_tries` times (about one placement in seven is the fast
  * one; ~5 ms per try), keeping the best placement seen, then waits until the driver's background wipe of
  * the freed candidates no longer shows.  max_tries <= 1: plain allocation.  Free both arrays with
- * mmdx_device_free(). */
+ * mmdx_device_free().  What the probe found (fast or not) is remembered per array address in a small process-wide
+ * table until mmdx_device_free(): mmdx_deform_batched consults it to pick the store flavour of its kernel
+ * (MMDX_OUT_STORES_* above) -- a performance hint only, results never depend on it. */
 typedef struct mmdx_placement_info {
     uint32_t struct_size;
     uint32_t tries;          /* allocations made                                                        */
