@@ -74,13 +74,26 @@ int main() {
     const size_t bytes = size_t(50000) * 1024 * 12;
     const size_t sizes[] = {size_t(2) << 20, size_t(8) << 20, size_t(32) << 20, size_t(128) << 20, 0};
     const char *names[] = {"vmm 2 MiB", "vmm 8 MiB", "vmm 32 MiB", "vmm 128 MiB", "vmm whole"};
-    for (int t = 0; t < 8; ++t) {
+    const int first_flavour = 3;                              // this run: 128 MiB chunks and whole-array chunks only
+    for (int t = 0; t < 10; ++t) {
         void *a, *b;
         CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
         std::printf("trial %d: hipMalloc %6.0f", t, run(a, b));
-        for (int k = 0; k < 5; ++k) {
+        for (int k = first_flavour; k < 5; ++k) {
             void *va = vmm_array(bytes, sizes[k]), *vb = vmm_array(bytes, sizes[k]);
             std::printf("   %s %6.0f", names[k], run(va, vb));
+            std::fflush(stdout);
+        }
+        {   // physically contiguous backing asked for explicitly: two allocations, then one allocation split in two
+            void *ca = nullptr, *cb = nullptr, *cc = nullptr;
+            hipError_t e1 = hipExtMallocWithFlags(&ca, bytes, hipDeviceMallocContiguous);
+            hipError_t e2 = hipExtMallocWithFlags(&cb, bytes, hipDeviceMallocContiguous);
+            if (e1 == hipSuccess && e2 == hipSuccess) std::printf("   contiguous x2 %6.0f", run(ca, cb));
+            else { std::printf("   contiguous x2 failed (%s)", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); (void)hipGetLastError(); }
+            const size_t half = (bytes + 4095) / 4096 * 4096;
+            hipError_t e3 = hipExtMallocWithFlags(&cc, 2 * half, hipDeviceMallocContiguous);
+            if (e3 == hipSuccess) std::printf("   contiguous 1 block %6.0f", run(cc, static_cast<char *>(cc) + half));
+            else { std::printf("   contiguous 1 block failed (%s)", hipGetErrorString(e3)); (void)hipGetLastError(); }
             std::fflush(stdout);
         }
         std::printf("  GB/s\n");
