@@ -132,6 +132,7 @@ def main():
                                                 device_select, device_synchronize)
     build.build()
     api.lib()
+    stamp = api.check_library_matches_tree()        # the loaded library was built from THIS tree's sources, or we stop here
     # HIP first, torch second: torch bundles its own HIP runtime; if it gets to initialise before this
     # process has touched the GPU through the system runtime libmmdx links against, the latter sees no
     # device.  So count / select / touch the device, THEN import torch for the gloo rendezvous.
@@ -164,7 +165,13 @@ def main():
     d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else args.shop_alloc)
     d_pal = DeviceBuffer.from_numpy(pals)
     d_w = DeviceBuffer.from_numpy(rates)
-    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    # the probe's verdict on these arrays travels with the call (mmdx.h: the library keeps no table of addresses)
+    base_flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    flags = base_flags | placement.get("store_flags", 0)
+    rates_b = rates.copy()
+    rates_b[0] = np.float32(0.25) if rates_b[0] != np.float32(0.25) else np.float32(0.5)
+    d_w2 = DeviceBuffer.from_numpy(rates_b)
+    flip = [0]
 
     def step():
         dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout, flags,
@@ -173,6 +180,11 @@ def main():
     def kernel_only_step():                 # the deform kernel alone: the morphed positions of the last step are reused
         dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout,
                               flags | api.MORPH_UNCHANGED, pos_scale)
+
+    def changing_step():                    # the shared morph state differs from the previous step's: the morph pass walks every time
+        flip[0] ^= 1
+        dm.deform_batched_raw(ni, (d_w2 if flip[0] else d_w).ptr, d_pal.ptr, d_a.ptr, d_b.ptr if d_b else None, layout, flags,
+                              pos_scale)
 
     def timed_batch(fn, n):
         """n back-to-back calls bracketed by ONE pair of HIP events on the launch stream; ms per call."""
@@ -236,8 +248,13 @@ def main():
     # kernel's duration in an uninstrumented stream, which is what a rocprofv3 kernel trace of this run shows too.
     # Three batches of K, the median is reported (one batch now and then catches a clock or placement hiccup: 0.2275 vs 0.2185-0.2198 ms
     # on otherwise identical runs); all three are kept in roofline.kernel_only_batches_ms.
+    pass_stats = dm.morph_pass_stats()      # (walks, device-side skips, host-side skips) up to the end of the timed region
     kernel_batches = [timed_batch(kernel_only_step, args.steps) for _ in range(3)]
     kernel_ms = sorted(kernel_batches)[1]
+    # ---- the same K steps with a morph state that CHANGES every step (two rate sets taking turns): flatten + walk + deform -----
+    timed_batch(changing_step, 5)
+    changing_ms = sorted(timed_batch(changing_step, args.steps) for _ in range(3))[1]
+    step()                                  # leave the headline's morph state behind
     # ---- the old figure, kept as a named extra: events around every kernel of K more steps ---------------------
     dm.profile_enable(True)
     for _ in range(args.steps):
@@ -253,8 +270,13 @@ def main():
     total_vertices = float(ni) * world * model.nv * args.steps
     value = total_vertices / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    deform_bytes, step_bytes = algorithmic_bytes_config3(model.nv, model.nb, model.nm, info.n_entries, ni,
-                                                         info.n_bdef1, info.n_bdef2, info.n_bdef4)
+    deform_bytes, walk_step_bytes = algorithmic_bytes_config3(model.nv, model.nb, model.nm, info.n_entries, ni,
+                                                              info.n_bdef1, info.n_bdef2, info.n_bdef4)
+    # Config 3 as BASELINE states it: ONE shared morph state, per-instance palettes.  The state does not change across the timed
+    # steps, the library notices (device-side comparison of the rates, mmdx.h MMDX_MORPH_UNCHANGED) and the morph pass skips its
+    # walk: the step's compulsory bytes are the deform kernel's plus the rates read twice.  The walking form is timed beside it.
+    walked_every_step = pass_stats[1] == 0 and pass_stats[2] == 0
+    step_bytes = walk_step_bytes if walked_every_step else deform_bytes + 2 * model.nm * 4
     if layout == api.OUT_VERTEX32:
         deform_bytes += ni * model.nv * 8 + model.nv * 8        # 32 B out + uv in
         step_bytes += ni * model.nv * 8 + model.nv * 8
@@ -283,6 +305,15 @@ def main():
                      "step_algorithmic_bytes": step_bytes,
                      "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "step_event_ms": ev_ms / args.steps,
+                     "step_form": ("default call form (device-resident shared rates, no MMDX_MORPH_UNCHANGED): " +
+                                   ("the morph pass walked the table on every step" if walked_every_step else
+                                    "rates unchanged across the timed steps, detected by the library on the device -- the morph "
+                                    "pass launched every step and skipped its walk")),
+                     "morph_pass_stats_at_end_of_timed_region": {"walks": pass_stats[0], "device_skips": pass_stats[1],
+                                                                 "host_skips": pass_stats[2]},
+                     # the morph state changes on every step (two rate sets in turn): flatten + walk + deform, median of 3 x K
+                     "changing_morph_state": {"ms_per_step": changing_ms, "step_algorithmic_bytes": walk_step_bytes,
+                                              "step_frac": walk_step_bytes / (changing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      # W warm-up + K steps right after set-up, no settle batches in front (max over ranks, wall clock)
                      "cold": {"ms_per_step": cold_ms, "step_frac": step_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      # per-kernel events on every launch (round 1's headline; flatters the kernel, see above)
@@ -290,9 +321,12 @@ def main():
                      "event_bracketed_frac": deform_bytes / (skin_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      # deform-kernel launches after the timed region, oldest first (trace post-processing)
                      "trace_segments": [["timed", args.steps], ["kernel_only", args.steps], ["kernel_only", args.steps],
-                                        ["kernel_only", args.steps], ["event_bracketed", args.steps]],
+                                        ["kernel_only", args.steps], ["changing_morph_state", 5 + 3 * args.steps + 1],
+                                        ["event_bracketed", args.steps]],
                      "output_placement": placement,
                      "kernel_source_sha": kernel_source_sha(),
+                     # the binary's own word on what it was built from, next to the hash of the tree (bench refuses a mismatch)
+                     "library_source_sha": stamp["library_source_sha"], "tree_source_sha": stamp["tree_source_sha"],
                      "settle_batches_step_ms": [round(x, 4) for x in settle_batches]},
     }
 
@@ -328,7 +362,9 @@ def main():
             p_a, p_b, p_info = dm.alloc_outputs(layout, ni, 1)
 
             def plain_step():
-                dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, p_a.ptr, p_b.ptr if p_b else None, layout, flags, pos_scale)
+                # (no hint: these arrays were not probed, the library's default for unknown arrays applies)
+                dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, p_a.ptr, p_b.ptr if p_b else None, layout,
+                                      base_flags | p_info.get("store_flags", 0), pos_scale)
             timed_batch(plain_step, 20)
             pl_ms = timed_batch(plain_step, args.steps)
             pl = {"ms_per_step": pl_ms, "vertices_per_s": ni * model.nv / (pl_ms * 1e-3),
@@ -389,7 +425,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         result["other_workloads"] = extras(api, synth, DeformModel, DeviceBuffer, dm, model)
 
-    d_pal.free(); d_w.free(); d_a.free()
+    d_pal.free(); d_w.free(); d_w2.free(); d_a.free()
     if d_b:
         d_b.free()
     dm.close()

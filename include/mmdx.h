@@ -54,7 +54,9 @@ extern "C" {
 
 /* 2: mmdx_skeleton_desc.create_flags (was reserved0), the physics seam and graph entry points, unknown flag bits are
  *    rejected, bench / debug entry points moved to mmdx_bench.h (same library). */
-#define MMDX_ABI_VERSION 2u
+/* 3: mmdx_placement_info.store_flags (the library keeps no table of array addresses any more: the caller carries the probe's
+ *    verdict into mmdx_deform_args.flags); shared morph rates that did not change are detected by the library itself. */
+#define MMDX_ABI_VERSION 3u
 
 typedef int32_t mmdx_status;
 enum {
@@ -150,14 +152,22 @@ enum {
                                          previous such call on this model (a crowd whose facial state
                                          changes less often than its poses): the morphed positions of that
                                          call are reused and the morph pass is skipped; morph_weights is
-                                         not read.  An error without such an earlier call.            */
+                                         not read.  An error without such an earlier call.
+                                         WITHOUT this flag the library finds out by itself (the reference's vertex_images_
+                                         depends on morph_rates_ only, L/motion/poser_impl.inl:362-386): shared rates in host
+                                         memory are compared with the ones of the pass whose result the handle holds and the
+                                         pass (launch and upload) is skipped when they are bit for bit the same; shared rates
+                                         in device memory are compared by the morph pass itself, on the device, which then
+                                         skips its walk over the morph table (the launch remains: ~2 us instead of ~9).  The
+                                         flag is the caller's promise and saves that launch too.                  */
     /* Hints for crowds whose outputs stream through the caches (device arrays of >= 512 MB per call): how the kernel
-       writes them.  By default the library decides: arrays from mmdx_crowd_output_alloc by what its probe measured
-       (fast store mode: cached non-temporal stores; otherwise write-through stores, ~5 % faster there, 2 % slower in
-       the fast mode), arrays it knows nothing about write-through (six plain allocations in seven are not in the fast
-       mode).  A caller who has measured its own arrays (mmdx_bench_store_pattern against mmdx_bench_fill,
-       mmdx_bench.h) can say so.  Results are identical either way; kernels without a write-through flavour ignore
-       the hint; the two exclude each other.                                                          */
+       writes them -- cached non-temporal stores (best where the arrays' physical backing is in the fast store mode, see
+       mmdx_crowd_output_alloc) or write-through stores (~5 % faster everywhere else, 2 % slower in the fast mode).
+       mmdx_crowd_output_alloc returns the right one for its arrays in mmdx_placement_info.store_flags; a caller who has
+       measured its own arrays (mmdx_bench_store_pattern against mmdx_bench_fill, mmdx_bench.h) can say so too.  Without
+       a hint such outputs are written through (six plain allocations in seven are not in the fast mode).  The decision
+       is made from the call's arguments alone: the library remembers nothing about array addresses.  Results are
+       identical either way; kernels without a write-through flavour ignore the hint; the two exclude each other.   */
     MMDX_OUT_STORES_WRITE_THROUGH = 1u << 5,
     MMDX_OUT_STORES_CACHED = 1u << 6
 };
@@ -287,15 +297,18 @@ MMDX_API mmdx_status mmdx_device_synchronize(void);
  * against a linear fill, and retries up to `max_tries` times (about one placement in seven is the fast
  * one; ~5 ms per try), keeping the best placement seen, then waits until the driver's background wipe of
  * the freed candidates no longer shows.  max_tries <= 1: plain allocation.  Free both arrays with
- * mmdx_device_free().  What the probe found (fast or not) is remembered per array address in a small process-wide
- * table until mmdx_device_free(): mmdx_deform_batched consults it to pick the store flavour of its kernel
- * (MMDX_OUT_STORES_* above) -- a performance hint only, results never depend on it. */
+ * mmdx_device_free() (or hipFree: the library keeps no record of the arrays).  What the probe found comes back in
+ * mmdx_placement_info.store_flags: OR it into mmdx_deform_args.flags of the crowd calls that write these arrays
+ * (MMDX_OUT_STORES_* above) -- a performance hint only, results never depend on it, and its lifetime is the caller's:
+ * it describes the physical backing of THIS allocation and is void once the arrays are freed. */
 typedef struct mmdx_placement_info {
     uint32_t struct_size;
     uint32_t tries;          /* allocations made                                                        */
     uint32_t probed;         /* 0: layout / vertex count not probe-able, plain allocation               */
     float store_GBs;         /* store-only replay on the returned arrays                                */
     float fill_GBs;          /* linear fill of the same bytes (the yardstick)                           */
+    uint32_t store_flags;    /* MMDX_OUT_STORES_CACHED (fast store mode found), MMDX_OUT_STORES_WRITE_THROUGH
+                                (not found), or 0 (not probed: the library's default applies)            */
 } mmdx_placement_info;
 MMDX_API mmdx_status mmdx_crowd_output_alloc(mmdx_model_t model, uint32_t n_instances, int32_t out_layout,
                                              uint32_t max_tries, void **out_a_device, void **out_b_device,

@@ -32,9 +32,18 @@ MMDX_API mmdx_status mmdx_profile_collect(mmdx_model_t model, uint32_t *n_calls,
 /* The launch-shape overrides for A/B runs (environment variables MMDX_GROUP, MMDX_THREADS, MMDX_LDS_TARGET,
  * MMDX_INTERLEAVE; tools/ab.py) are read once per process; this re-reads them.  Not for product use. */
 MMDX_API void mmdx_debug_reload_env(void);
-/* Which store flavour the model's last mmdx_deform_batched call asked of its kernel: 0 = cached non-temporal stores, 1 =
- * write-through (mmdx.h, MMDX_OUT_STORES_*; kernels without a write-through flavour run their usual stores either way). */
+/* Which store flavour the kernel of the model's last mmdx_deform_batched call ran with: 0 = cached non-temporal stores, 1 =
+ * write-through (mmdx.h, MMDX_OUT_STORES_*; 1 only where the launched kernel has that flavour). */
 MMDX_API mmdx_status mmdx_debug_last_store_policy(mmdx_model_t model, int32_t *write_through);
+/* What became of the model's shared morph passes so far (mmdx.h, MMDX_MORPH_UNCHANGED): launches that walked the morph table,
+ * launches whose device-side comparison found the rates unchanged and skipped the walk, and calls whose host-side comparison
+ * skipped the launch altogether.  Waits for the model's stream. */
+MMDX_API mmdx_status mmdx_debug_morph_pass_stats(mmdx_model_t model, uint32_t *walks, uint32_t *device_skips,
+                                                 uint32_t *host_skips);
+/* The revision of the sources this library was built from: SHA-1 over the translation units and headers of build.py's list,
+ * in that order, embedded at build time (-DMMDX_SOURCE_SHA).  bench.py and smoke() print it next to the same hash of the files
+ * in the tree and refuse to run when they differ: a timed library is provably the committed code. */
+MMDX_API const char *mmdx_build_source_sha(void);
 /* Device-to-device streaming copy / fill timed with HIP events: the practical HBM ceiling printed
  * next to the roofline.  bytes_moved = 2*bytes for copy, bytes for fill. */
 MMDX_API mmdx_status mmdx_bench_copy(void *dst_device, const void *src_device, size_t bytes,

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMDX_LIB") or os.path.join(HERE, "libmmdx.so")   # MMDX_LIB: A/B of builds (tools/)
 
 OK = 0
-ABI_VERSION = 2          # include/mmdx.h MMDX_ABI_VERSION
+ABI_VERSION = 3          # include/mmdx.h MMDX_ABI_VERSION
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "BAD_INDEX", 3: "NO_DEVICE", 4: "HIP", 5: "OUT_OF_MEMORY",
              6: "UNSUPPORTED"}
 
@@ -94,6 +94,8 @@ SIGNATURES = {
     "mmdx_device_synchronize": (C.c_int32, []),
     "mmdx_debug_reload_env": (None, []),
     "mmdx_debug_last_store_policy": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mmdx_debug_morph_pass_stats": (C.c_int32, [C.c_void_p, _u32p, _u32p, _u32p]),
+    "mmdx_build_source_sha": (C.c_char_p, []),
     "mmdx_bench_copy": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
     "mmdx_bench_fill": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, _f32p]),
     "mmdx_bench_store_pattern": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, _f32p]),
@@ -159,6 +161,22 @@ def lib() -> C.CDLL:
             raise RuntimeError("libmmdx.so ABI version mismatch")
         _lib = l
     return _lib
+
+
+def library_source_sha() -> str:
+    """The source revision stamped into the loaded library (mmdx_bench.h, mmdx_build_source_sha)."""
+    return (lib().mmdx_build_source_sha() or b"").decode()
+
+
+def check_library_matches_tree() -> dict:
+    """The loaded library must have been built from the sources in this tree: returns both hashes, raises on a mismatch
+    (MMDX_LIB experiment builds are exempt: tools/ compare variants on purpose)."""
+    from . import build
+    lib_sha, tree_sha = library_source_sha(), build.source_sha()
+    if lib_sha != tree_sha and not os.environ.get("MMDX_LIB"):
+        raise RuntimeError(f"libmmdx.so was built from other sources than this tree's (library {lib_sha}, tree {tree_sha}): "
+                           "rebuild with `python -m simple_mmd_renderer_amd.build`")
+    return {"library_source_sha": lib_sha, "tree_source_sha": tree_sha}
 
 
 def check(status: int) -> None:

@@ -2,10 +2,11 @@
 
     python -m simple_mmd_renderer_amd.build [--force]
 
-One explicit hipcc command, no build system: the product is a dozen translation units (kernels_fast.hip is kernels.hip
-compiled a second time with multiply-add contraction allowed, for models created with MMDX_CREATE_FAST_MATH).  The .so is
-git-ignored but travels to the GPU box with the working tree.  -ffp-contract=off is part of the
-contract (bit-exact parity with the reference's CPU arithmetic), not a debug flag.
+Explicit hipcc commands, no build system: one `hipcc -c` per translation unit (a dozen; in parallel; objects cached by content
+under build/obj), one link (kernels_fast.hip is kernels.hip compiled a second time with multiply-add contraction allowed, for
+models created with MMDX_CREATE_FAST_MATH).  The .so is git-ignored but travels to the GPU box with the working tree and carries
+the hash of the sources it was built from (mmdx_build_source_sha): freshness is decided by content, never by timestamps.
+-ffp-contract=off is part of the contract (bit-exact parity with the reference's CPU arithmetic), not a debug flag.
 """
 from __future__ import annotations
 
@@ -31,22 +32,109 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def flags() -> list[str]:
+def source_sha() -> str:
+    """SHA-1 over everything the library is built from (sources and headers in the order listed, the flags, experiment knobs):
+    embedded in the binary (mmdx_build_source_sha) and compared by build(), bench.py and smoke() -- the loaded library is
+    provably built from the files in the tree, whatever the timestamps say."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in SOURCES + HEADERS:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(flags()).encode())
+    return h.hexdigest()
+
+
+def library_sha(path: str = None) -> str | None:
+    """The stamp inside a built library, read from the file's bytes (no dlopen); None if missing / unstamped."""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    data = open(path, "rb").read()
+    tag = b"mmdx-source-sha:"
+    i = data.find(tag)
+    if i < 0:
+        return None
+    sha = data[i + len(tag): i + len(tag) + 40]
+    return sha.decode() if len(sha) == 40 and all(c in b"0123456789abcdef" for c in sha) else None
+
+
+STAMPED = "bench_api.cpp"      # the one translation unit that carries -DMMDX_SOURCE_SHA (mmdx_build_source_sha lives there)
+INCLUDES = {"kernels_fast.hip": ["kernels.hip"]}      # sources that #include other sources
+
+
+def flags(stamp: bool = False) -> list[str]:
     extra = []
+    if stamp:
+        extra.append('-DMMDX_SOURCE_SHA="%s"' % source_sha())
     if os.environ.get("MMDX_BUILD_DEFS"):      # tools/ experiments only
         extra += ["-D" + d for d in os.environ["MMDX_BUILD_DEFS"].split(",")]
     if os.environ.get("MMDX_BUILD_TILE"):
         extra.append("-DMMDX_TILE=" + os.environ["MMDX_BUILD_TILE"])
-    return extra + [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+    return extra + [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
             "-fvisibility=hidden", "-Wall", "-Wextra", "-Wno-unused-parameter"]
 
 
+OBJ_DIR = os.path.join(HERE, "..", "build", "obj")
+
+
+def _compile_one(args):
+    src, obj, cmd = args
+    if os.path.exists(obj):
+        return obj, 0, ""
+    tmp = obj + ".tmp.%d" % os.getpid()
+    r = subprocess.run(cmd + ["-c", "-x", "hip", src, "-o", tmp], capture_output=True, text=True)
+    if r.returncode == 0:
+        os.replace(tmp, obj)
+    elif os.path.exists(tmp):
+        os.remove(tmp)
+    return obj, r.returncode, r.stdout + r.stderr
+
+
+def _objects(verbose: bool) -> list[str]:
+    """One object per translation unit, keyed by the hash of what goes into it -- its source (and sources it #includes), every
+    header, the flags -- so a header edit rebuilds all of them, an edit of one source only that one (plus the stamped unit), and
+    an experiment's -D never picks up the default build's objects.  Compiled in parallel."""
+    import concurrent.futures as cf
+    import hashlib
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    common = hashlib.sha1(" ".join(flags()).encode())
+    for f in HEADERS:
+        common.update(open(os.path.join(CSRC, f), "rb").read())
+    jobs = []
+    for src in SOURCES:
+        stamped = src == STAMPED
+        h = common.copy()
+        for f in [src] + INCLUDES.get(src, []):
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+        if stamped:
+            h.update(source_sha().encode())
+        jobs.append((os.path.join(CSRC, src), os.path.join(OBJ_DIR, "%s-%s.o" % (os.path.splitext(src)[0], h.hexdigest()[:16])),
+                     [hipcc()] + flags(stamp=stamped)))
+    cmd = [hipcc()] + flags()
+    if verbose:
+        print(" ".join(cmd + ["-c", "-x", "hip", "<each of: %s>" % " ".join(SOURCES)]))
+    workers = max(1, min(len(jobs), len(os.sched_getaffinity(0))))
+    with cf.ThreadPoolExecutor(workers) as ex:
+        done = list(ex.map(_compile_one, jobs))
+    for obj, rc, log in done:
+        if rc != 0:
+            sys.stderr.write(log)
+            raise RuntimeError("hipcc failed for " + os.path.basename(obj))
+        if verbose and log:
+            sys.stderr.write(log)
+    # older revisions' objects: keep the cache from growing without bound
+    keep = {o for o, _, _ in done}
+    olds = sorted((f for f in os.listdir(OBJ_DIR) if f.endswith(".o") and os.path.join(OBJ_DIR, f) not in keep),
+                  key=lambda f: os.path.getmtime(os.path.join(OBJ_DIR, f)))
+    for f in olds[:-4 * len(SOURCES)] if len(olds) > 4 * len(SOURCES) else []:
+        os.remove(os.path.join(OBJ_DIR, f))
+    return [o for o, _, _ in done]
+
+
 def up_to_date() -> bool:
-    if not os.path.exists(LIB):
-        return False
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return all(os.path.getmtime(d) <= t for d in deps)
+    """By content, not by timestamp: the library's embedded stamp equals the hash of the sources in the tree."""
+    return library_sha() == source_sha()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -61,7 +149,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not force and up_to_date():
             return LIB
         tmp = LIB + ".tmp.%d" % os.getpid()
-        cmd = [hipcc()] + flags() + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+        objs = _objects(verbose)
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", tmp]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -12,7 +12,6 @@
 #include <chrono>
 #include <cstring>
 #include <mutex>
-#include <unordered_map>
 #include <new>
 #include <string>
 #include <thread>
@@ -64,25 +63,17 @@ struct mmdx_graph_s {
 namespace {
 std::mutex g_graph_mu;          // graph <-> handle links (rare operations: record, destroy)
 
-// What mmdx_crowd_output_alloc learned about the arrays it handed out: first array -> "stores at the fast rate".  The crowd call
-// picks the store flavour of its copy-out from it (write_through_for); entries leave with mmdx_device_free.
-std::mutex g_place_mu;
-std::unordered_map<const void *, bool> g_place_fast;
-
-// Store flavour of a crowd launch (kernels.hip CopyFast): `nt` where the arrays are known to sit in the fast store mode,
-// `sc1 nt` (write-through) where they are known not to -- and where nothing is known, because six plain allocations in seven are
-// not (expected cost of the wrong guess: 2 % on a fast pair against 4.6-5 % on the others).  Only outputs large enough to stream
-// through the caches (>= 512 MB) are considered, and only the kernels that have the flavour (kernels.hip pick()).
-// Caller's hints first, then MMDX_STORE_WT=0 / 1 (A/B), then the registry.
-bool write_through_for(const void *out_a, size_t out_bytes, uint32_t flags) {
+// Store flavour of a crowd launch (kernels.hip CopyFast), decided from the CALL alone -- no table of addresses, no state behind the
+// boundary: the caller's hint first (mmdx_placement_info.store_flags hands it the probe's verdict for arrays from
+// mmdx_crowd_output_alloc), then MMDX_STORE_WT=0 / 1 (A/B runs), then the default for arrays nothing is known about: outputs large
+// enough to stream through the caches (>= 512 MB per call) are written through, because six plain allocations in seven are not in
+// the fast store mode (expected cost of the wrong guess: 2 % on a fast pair against 4.6-5 % on the others).
+bool write_through_for(size_t out_bytes, uint32_t flags) {
     if (flags & MMDX_OUT_STORES_WRITE_THROUGH) return true;
     if (flags & MMDX_OUT_STORES_CACHED) return false;
-    static const int env = env_int("MMDX_STORE_WT", -1);
+    const int env = launch_overrides().store_wt;
     if (env == 0 || env == 1) return env == 1;
-    if (out_bytes < (size_t(512) << 20)) return false;
-    std::lock_guard<std::mutex> lk(g_place_mu);
-    const auto it = g_place_fast.find(out_a);
-    return it == g_place_fast.end() ? true : !it->second;
+    return out_bytes >= (size_t(512) << 20);
 }
 }
 void mmdx::graph_note_handle(mmdx_model_s *model, GraphPin *pin) {
@@ -192,6 +183,12 @@ mmdx_status upload_model(mmdx_model_s *m) {
     if (p.ns) {
         HIP_TRY(m->morphed.ensure(size_t(p.nv) * 12));
         t += size_t(p.nv) * 12;
+        // which rates `morphed` was last computed from (kernels.hpp, RatesSeen): nothing yet
+        const size_t seen_bytes = (size_t(kSeenRates) + p.nm) * 4;
+        HIP_TRY(m->seen.ensure(seen_bytes));
+        HIP_TRY(hipMemset(m->seen.ptr, 0, seen_bytes));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        t += seen_bytes;
     }
     return MMDX_OK;
 }
@@ -203,7 +200,7 @@ void free_model(mmdx_model_s *m) {
         for (DevBuf *b : {&m->tiles, &m->spos, &m->snrm, &m->suv, &m->perm, &m->skin1, &m->skin2_ids,
                           &m->skin2_w, &m->skin4_ids, &m->skin4_w, &m->bone_list, &m->ell,
                           &m->entries, &m->slot_top, &m->chain_off, &m->chain_rate, &m->pal, &m->rates,
-                          &m->wslot, &m->morphed, &m->out_a, &m->out_b})
+                          &m->wslot, &m->morphed, &m->seen, &m->out_a, &m->out_b})
             b->release();
         if (m->bounce) (void)hipHostFree(m->bounce);
         if (m->bounce_in) (void)hipHostFree(m->bounce_in);
@@ -250,7 +247,8 @@ int mmdx::env_int(const char *name, int dflt) {
 LaunchOverrides mmdx::read_launch_overrides() {
     return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
             env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
-            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1)};
+            env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1),
+            env_int("MMDX_STORE_WT", -1), env_int("MMDX_MORPH_AUTOSKIP", 1)};
 }
 LaunchOverrides &mmdx::launch_overrides() {
     static LaunchOverrides o = read_launch_overrides();
@@ -293,6 +291,9 @@ bool mmdx::graph_recording() { return tl_recording_depth > 0; }
 // hipFree is one of the calls the runtime refuses on a thread whose stream is recording (it would also invalidate the recording):
 // a handle destroyed in that window parks its blocks here, mmdx_graph_end frees them.
 static thread_local std::vector<void *> tl_deferred_free;
+// ... and so are the stream / event / page-locked-memory calls of a whole handle's teardown: a model destroyed on a thread that is
+// recording (another model's graph) is only cut off from its graphs here; its resources go at mmdx_graph_end.
+static thread_local std::vector<mmdx_model_s *> tl_deferred_models;
 void mmdx::device_free_or_defer(void *ptr) {
     if (!ptr) return;
     if (tl_recording_depth > 0) tl_deferred_free.push_back(ptr);
@@ -414,6 +415,12 @@ mmdx_status mmdx_model_destroy(mmdx_model_t model) {
         mmdx_graph_t dropped = nullptr;
         (void)mmdx_graph_end(model, &dropped);
         mmdx_graph_destroy(dropped);
+    }
+    if (tl_recording_depth > 0 && model->device >= 0) {
+        // this thread is (still) recording another model's graph: no wait, no stream / event / host-memory call now
+        graph_drop_handle(&model->pin);
+        tl_deferred_models.push_back(model);
+        return MMDX_OK;
     }
     if (model->device >= 0) {
         (void)hipSetDevice(model->device);
@@ -576,11 +583,24 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // kernel (every workgroup repeats its tile's walk; no separate launch: 8.8 vs 10.1 us for 2 instances of the 50k
     // model, break-even at 8, tools/probes/shared_ab.py); larger crowds run the morph pass once, in front (257 vs 269 us for
     // 1024 instances) -- or not at all when the caller declares the rates unchanged since the last such call.
-    const bool unchanged = shared && ni > 1 && (a->flags & MMDX_MORPH_UNCHANGED);
+    bool unchanged = shared && ni > 1 && (a->flags & MMDX_MORPH_UNCHANGED);
     if (unchanged && !m->morphed_valid)
         return fail(MMDX_ERR_INVALID_ARGUMENT, "MMDX_MORPH_UNCHANGED without an earlier MMDX_WEIGHTS_SHARED crowd call on this model");
     int morph = kMorphNone;
     const int sf = launch_overrides().shared_fused;          // 0: never for crowds, 1: small crowds (default), 2: always
+    // The same without the caller's promise: vertex_images_ depends on morph_rates_ only (poser_impl.inl:362-386), so a crowd call
+    // whose shared rates are, bit for bit, those of the morph pass whose result this handle still holds needs no morph pass.
+    // Rates in HOST memory are compared here (memcmp with the copy kept of the last pass's), the launch and the upload are skipped;
+    // rates in DEVICE memory are compared by morph_apply_kernel itself, which then skips its walk (RatesSeen, kernels.hpp).
+    const bool autoskip = launch_overrides().morph_autoskip != 0;
+    if (m->pin.replayed.exchange(false, std::memory_order_acq_rel)) m->host_rates_valid = false;   // a graph replay ran a morph pass
+    const bool crowd_pass = p.ns && shared && ni > 1 && !(p.ns <= kMaxFusedSlots && (sf == 2 || (sf == 1 && ni <= 8)));
+    const bool host_rates_call = crowd_pass && !unchanged && !(a->flags & MMDX_WEIGHTS_ON_DEVICE);
+    if (host_rates_call && autoskip && m->morphed_valid && m->host_rates_valid && m->host_rates.size() == p.nm &&
+        std::memcmp(m->host_rates.data(), a->morph_weights, size_t(p.nm) * 4) == 0) {
+        unchanged = true;
+        ++m->host_skips;
+    }
     const bool gather_in_kernel = ni == 1 || (p.ns <= kMaxFusedSlots && !unchanged && (sf == 2 || (sf == 1 && ni <= 8)));
     if (p.ns) morph = shared ? (gather_in_kernel ? kMorphFused1 : kMorphShared) : kMorphFused4;
     if (morph != kMorphNone) {
@@ -600,6 +620,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         f.chain_rate = static_cast<const float *>(m->chain_rate.ptr);
         f.nm = p.nm; f.ns = p.ns; f.niw = niw;
         f.quad = morph == kMorphFused4 ? 1u : 0u;
+        f.seen = nullptr;
         const size_t rows = f.quad ? size_t((niw + 3) / 4) * 4 : niw;
         HIP_TRY(m->wslot.ensure(rows * (size_t(p.ns) + 1) * 4));
         f.out = static_cast<float *>(m->wslot.ptr);
@@ -609,8 +630,10 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (morph == kMorphShared && unchanged) {
             // nothing to launch: `morphed` holds the positions
         } else if (morph == kMorphShared && p.ns <= kMaxFusedSlots) {
+            if (autoskip) f.seen = static_cast<uint32_t *>(m->seen.ptr);
             HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, &f, st));      // flatten fused in: one launch
         } else if (morph == kMorphFused1) {
+            if (ni > 1) dp.morph_seen = static_cast<uint32_t *>(m->seen.ptr);   // it overwrites `morphed`: the record is void after it
             // A single frame (ni == 1) leaves the model's kept positions alone: they belong to the last SHARED CROWD call
             // (MMDX_MORPH_UNCHANGED is documented against that one), whichever kernel the frame takes.
             if (ni == 1) dp.morphed = nullptr;
@@ -619,7 +642,17 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
             dp.nm = p.nm;
         } else {
             HIP_TRY(launch_flatten(f, st));
-            if (morph == kMorphShared) HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, nullptr, st));
+            if (morph == kMorphShared) {
+                HIP_TRY((fast ? launch_morph_apply_fast : launch_morph_apply)(p.f16, dp, nullptr, st));
+                HIP_TRY(hipMemsetAsync(m->seen.ptr, 0, 4, st));       // this (rare: > 8192 slots) pass keeps no record of its rates
+            }
+        }
+        // the host's own record: the rates of the pass `morphed` now holds, when they were host memory
+        if (morph == kMorphShared && !unchanged) {
+            m->host_rates_valid = host_rates_call;
+            if (host_rates_call) m->host_rates.assign(a->morph_weights, a->morph_weights + p.nm);
+        } else if (morph == kMorphFused1 && ni > 1) {
+            m->host_rates_valid = false;
         }
         if (pev) HIP_TRY(hipEventRecord(pev[3], st));
         if (morph == kMorphShared || (morph == kMorphFused1 && ni > 1)) m->morphed_valid = true;   // kept by either path
@@ -666,9 +699,6 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         }
     }
     dp.out_aligned = ((reinterpret_cast<uintptr_t>(dp.out_a) | reinterpret_cast<uintptr_t>(dp.out_b)) & 15) == 0;
-    // outputs in device memory only: stores into mapped host memory cross PCIe whatever their cache bits say
-    dp.write_through = out_dev && write_through_for(dp.out_a, bytes_a + bytes_b, a->flags) ? 1u : 0u;
-    m->last_write_through = dp.write_through != 0;
 
     // ---- workgroup shape ------------------------------------------------------------------------------
     // 256 threads / two vertex slots per lane everywhere except the per-instance-morph path: there one slot
@@ -682,6 +712,11 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         uint32_t so, wo;
         if (deform_lds_bytes(512, layout, morph, 8, p.max_tile_bones, p.ns, &so, &wo) > 160 * 1024) threads = 256;
     }
+    // ---- store flavour: only where the launch shape has the write-through flavour, and only for outputs in device memory (stores
+    // into mapped host memory cross PCIe whatever their cache bits say) ------------------------------------------------------------
+    dp.write_through = out_dev && deform_has_write_through(threads, int(layout), morph, p.f16, dp.tile_order != 0) &&
+                       write_through_for(bytes_a + bytes_b, a->flags) ? 1u : 0u;
+    m->last_write_through = dp.write_through != 0;
     // ---- group size (instances per workgroup) from the LDS budget ---------------------------------
     const uint32_t gmin = morph == kMorphFused4 ? (threads == 512 ? 8u : 4u) : 1u;
     uint32_t group = gmin;
@@ -696,9 +731,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         // write-through stores go to arrays that are not in the fast store mode; there 8 instances per workgroup (four workgroups
         // per CU, half the open output streams each) beat 16 by 3-8 % -- 218-224 vs 225-241 us on four such pairs, while on a fast
         // pair 16 wins (204 vs 211): profiles/r03/shape_sweep_write_through*.txt
-        if (dp.write_through && threads == 256 && layout == MMDX_OUT_SOA && !p.f16 && !dp.tile_order &&
-            (morph == kMorphNone || morph == kMorphShared))
-            g = std::min(g, 8u);
+        if (dp.write_through) g = std::min(g, 8u);
         g = std::max(g / gmin * gmin, gmin);
         const uint32_t ni_up = (ni + gmin - 1) / gmin * gmin;
         g = std::min(g, ni_up);
@@ -871,7 +904,15 @@ mmdx_status mmdx_graph_begin(mmdx_model_t m) {
     if (m->capturing) return fail(MMDX_ERR_INVALID_ARGUMENT, "this model is already recording a graph");
     if (m->profile) return fail(MMDX_ERR_INVALID_ARGUMENT, "mmdx_profile_enable and graph recording exclude each other");
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (tl_recording_depth > 0) {
+        // a second recording on a thread that is already recording: drain this model's stream by polling (a blocking wait is one
+        // of the calls a recording thread should not make)
+        hipError_t q;
+        while ((q = hipStreamQuery(m->stream)) == hipErrorNotReady) std::this_thread::yield();
+        HIP_TRY(q);
+    } else {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
     HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
     m->capturing = true;
     m->capture_thread = std::this_thread::get_id();
@@ -905,9 +946,19 @@ mmdx_status mmdx_graph_end(mmdx_model_t m, mmdx_graph_t *out) {
     }
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(m->stream, &g);
-    if (tl_recording_depth == 0) {                      // blocks of handles destroyed while this thread was recording
+    if (tl_recording_depth == 0) {                      // handles destroyed while this thread was recording, and their blocks
+        std::vector<mmdx_model_s *> models;
+        models.swap(tl_deferred_models);
+        for (mmdx_model_s *dm : models) {
+            if (dm->device >= 0) {
+                (void)hipSetDevice(dm->device);
+                (void)hipStreamSynchronize(dm->stream);
+            }
+            free_model(dm);
+        }
         for (void *p : tl_deferred_free) (void)hipFree(p);
         tl_deferred_free.clear();
+        (void)hipSetDevice(m->device);
     }
     if (poisoned) {
         if (g) (void)hipGraphDestroy(g);
@@ -940,6 +991,10 @@ mmdx_status mmdx_graph_launch(mmdx_graph_t g) {
     if (!g->valid.load(std::memory_order_acquire))
         return fail(MMDX_ERR_INVALID_ARGUMENT, "a model, skeleton or motion this graph was recorded from has been destroyed: "
                                                "the graph holds freed device addresses and cannot be replayed");
+    {   // a replay may recompute a model's morphed positions from rates the host never saw: its host-side record of them is void
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        for (GraphPin *p : g->pins) p->replayed.store(true, std::memory_order_release);
+    }
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(g->exec), static_cast<hipStream_t>(g->stream)));
     return MMDX_OK;
@@ -980,13 +1035,7 @@ mmdx_status mmdx_host_free(void *ptr) {
 }
 
 mmdx_status mmdx_device_free(void *ptr) {
-    if (ptr) {
-        {
-            std::lock_guard<std::mutex> lk(g_place_mu);
-            g_place_fast.erase(ptr);
-        }
-        HIP_TRY(hipFree(ptr));
-    }
+    if (ptr) HIP_TRY(hipFree(ptr));
     return MMDX_OK;
 }
 
@@ -1109,15 +1158,15 @@ mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_
     HIP_TRY(hipDeviceSynchronize());
     *out_a = best.a;
     *out_b = best.b;
-    if (can_probe && fill_gbs > 0.f) {
-        std::lock_guard<std::mutex> lk(g_place_mu);
-        g_place_fast[best.a] = best.gbs >= 0.92f * fill_gbs;
-    }
     if (info) {
         info->tries = tries;
         info->probed = can_probe ? 1u : 0u;
         info->store_GBs = best.gbs;
         info->fill_GBs = fill_gbs;
+        // the probe's verdict, for the caller to pass on in mmdx_deform_args.flags (nothing is remembered here)
+        info->store_flags = can_probe && fill_gbs > 0.f ? (best.gbs >= 0.92f * fill_gbs ? uint32_t(MMDX_OUT_STORES_CACHED)
+                                                                                         : uint32_t(MMDX_OUT_STORES_WRITE_THROUGH))
+                                                        : 0u;
     }
     return MMDX_OK;
 }

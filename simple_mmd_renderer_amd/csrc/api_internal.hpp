@@ -58,6 +58,8 @@ struct LaunchOverrides {
     int frame_threads;
     int shared_fused;   // MMDX_SHARED_FUSED: crowds with a shared facial state gather the morphs inside the deform kernel: 0 never,
                         // 1 up to 8 instances (default), 2 always (A/B, tests)
+    int store_wt;       // MMDX_STORE_WT: 0 / 1 force cached / write-through stores where the caller gave no hint (A/B); -1 default
+    int morph_autoskip; // MMDX_MORPH_AUTOSKIP: 0 turns the automatic "shared rates unchanged" detection off (A/B); 1 default
 };
 LaunchOverrides read_launch_overrides();
 LaunchOverrides &launch_overrides();
@@ -85,7 +87,11 @@ struct mmdx_model_s {
         ell, entries, slot_top, chain_off, chain_rate;
     // per-call scratch (grown on demand, reused)
     mmdx::DevBuf pal, rates, wslot, morphed, out_a, out_b;
+    mmdx::DevBuf seen;              // RatesSeen record (kernels.hpp): the rates `morphed` was last computed from, device side
     bool morphed_valid = false;     // `morphed` holds the result of a shared morph pass (MMDX_MORPH_UNCHANGED)
+    std::vector<float> host_rates;  // ... and the host's copy of those rates when they came from host memory
+    bool host_rates_valid = false;
+    uint32_t host_skips = 0;        // crowd calls whose morph pass the host-side comparison skipped (mmdx_debug_morph_pass_stats)
     bool capturing = false;         // between mmdx_graph_begin and mmdx_graph_end: the stream records
     std::thread::id capture_thread; // ... begun on this thread (thread-local capture mode: it must end there too)
     mmdx::GraphPin pin;                   // graphs that hold addresses of this model's scratch buffers

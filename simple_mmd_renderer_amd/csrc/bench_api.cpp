@@ -83,6 +83,29 @@ mmdx_status mmdx_debug_last_store_policy(mmdx_model_t model, int32_t *write_thro
     return MMDX_OK;
 }
 
+mmdx_status mmdx_debug_morph_pass_stats(mmdx_model_t model, uint32_t *walks, uint32_t *device_skips, uint32_t *host_skips) {
+    if (!model || !walks || !device_skips || !host_skips) return fail(MMDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *walks = *device_skips = 0;
+    *host_skips = model->host_skips;
+    if (model->device < 0 || !model->seen.ptr) return MMDX_OK;
+    HIP_TRY(hipSetDevice(model->device));
+    HIP_TRY(hipStreamSynchronize(model->stream));
+    uint32_t w[2] = {0, 0};
+    HIP_TRY(hipMemcpy(w, static_cast<const uint32_t *>(model->seen.ptr) + kSeenWalks, sizeof(w), hipMemcpyDeviceToHost));
+    *walks = w[0];
+    *device_skips = w[1];
+    return MMDX_OK;
+}
+
+#ifndef MMDX_SOURCE_SHA
+#define MMDX_SOURCE_SHA "unstamped"
+#endif
+// (the "mmdx-source-sha:" prefix lets build.py find the stamp in the file without loading it)
+const char *mmdx_build_source_sha(void) {
+    static const char stamp[] = "mmdx-source-sha:" MMDX_SOURCE_SHA;
+    return stamp + sizeof("mmdx-source-sha:") - 1;
+}
+
 static mmdx_status bench_stream_op(void *dst, const void *src, size_t bytes, int32_t iters, float *avg_ms) {
     if (!dst || !avg_ms || iters <= 0 || bytes < 16) return fail(MMDX_ERR_INVALID_ARGUMENT, "bad argument");
     hipEvent_t e0, e1;

@@ -18,6 +18,8 @@ struct GraphPin {
     std::atomic<int> pins{0};             // live graphs that hold addresses of this handle's buffers
     std::vector<mmdx_graph_s *> graphs;   // guarded by the registry's mutex (api.cpp)
     std::vector<mmdx_model_s *> recorders;   // models whose recording IN PROGRESS has used this handle (same mutex)
+    std::atomic<bool> replayed{false};    // a graph holding this handle was replayed since the handle last looked (a model's host-side
+                                          // record of its morph rates is void then)
 };
 
 // A library call is about to enqueue work of `pin`'s handle on `model`'s stream: if that stream is recording, the

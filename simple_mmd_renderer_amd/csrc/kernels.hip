@@ -62,15 +62,18 @@ __device__ __forceinline__ unsigned short f2h(float x) {
     return __builtin_bit_cast(unsigned short, _Float16(x));  // v_cvt_f16_f32, round to nearest even
 }
 
-// ---- cache policy of the OUTPUT stores (build-time A/B knob, tools/probes/store_policy_ab.py) --------------------------------
-// 98.7 % of the crowd kernel's HBM bytes are write-once stores.  MMDX_STORE_POLICY: 0 plain (the line stays in the XCD's L2
-// until evicted), 1 `nt` (non-temporal hint), 2 `sc1`, 3 `sc0 sc1` (write-through: the line is dropped from L2), 4 `sc1 nt`,
-// 5 `sc0 nt` -- MI355X_MICROARCH.md, "stores of each flavour".  Shipped: 1.  Measured interleaved on the same arrays
-// (profiles/r03/store_policy_*.txt): nt takes the crowd kernel from 218.7 to 206.2 us (fast placement; 264 -> 253 on a slow
-// one), the 32-byte-vertex crowd from 271 to 246, config 3' from 382 to 341, config 5 x 64 from 144 to 136; sc1 / sc0 sc1 change
-// nothing on a fast placement and gain 3 % on a slow one.  Results are bit-identical under every policy.
+// ---- cache policy of the OUTPUT stores ------------------------------------------------------------------------------------------
+// 98.7 % of the crowd kernel's HBM bytes are write-once stores.  MMDX_STORE_POLICY (build-time A/B knob): 0 plain (the line stays
+// in the XCD's L2 until evicted), 1 `nt` (non-temporal hint).  Shipped: 1 -- measured interleaved on the same arrays
+// (profiles/r03/store_policy_*.txt): nt takes the crowd kernel from 218.7 to 206.2 us (fast placement; 264 -> 253 on a slow one),
+// the 32-byte-vertex crowd from 271 to 246, config 3' from 382 to 341, config 5 x 64 from 144 to 136.  Both are compiler-visible
+// stores, bit-identical results.  The write-through flavour (`sc1 nt`) exists ONLY as the buffer-store builtin of CopyFast below:
+// round 3's inline-asm `sc1` flavours (policies 2-5) were invisible to the hazard recogniser and corrupted results -- removed.
 #ifndef MMDX_STORE_POLICY
 #define MMDX_STORE_POLICY 1
+#endif
+#if MMDX_STORE_POLICY != 0 && MMDX_STORE_POLICY != 1
+#error "MMDX_STORE_POLICY: 0 (plain) or 1 (nt); the inline-asm sc0/sc1 flavours of round 3 corrupted data and no longer exist"
 #endif
 #ifndef MMDX_WALK_ZPAIR
 #define MMDX_WALK_ZPAIR 1          // build-time A/B knob of the per-instance-morph walk (see there): z-pairing on (round 3: -2 % config 5 x 64, -1.5 % config 2 x 64, config 3' even; profiles/r03/walk_zpair_ab.txt)
@@ -79,14 +82,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(float4 *dst, const float4 v) {
 #if MMDX_STORE_POLICY == 1
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(dst));
-#elif MMDX_STORE_POLICY == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
-#elif MMDX_STORE_POLICY == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
-#elif MMDX_STORE_POLICY == 4
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
-#elif MMDX_STORE_POLICY == 5
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(dst), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
 #else
     *dst = v;
 #endif
@@ -214,8 +209,8 @@ __device__ __forceinline__ void copy_out2(const unsigned char *imgA, TA *outA, s
 // the XCD's L2.  On output arrays whose physical backing is in the slow store mode (six plain allocations in
 // seven) the SoA crowd kernel runs 4.6-5.0 % faster with it (251.6 -> 240.0 us), in the fast mode 2 % slower (207.0 -> 211.4):
 // profiles/r03/store_policy_buffer_builtin_ab*.txt -- so the host picks per launch (api.cpp).  Issued through the buffer-store
-// builtin: the compiler sees the instruction and keeps its data hazards (the inline-asm flavours of MMDX_STORE_POLICY did not,
-// and corrupted results); descriptor = this instance's piece of the array (wave-uniform), lane offset in bytes.
+// builtin: the compiler sees the instruction and keeps its data hazards (round 3's inline-asm flavours did not, and corrupted
+// results: removed); descriptor = this instance's piece of the array (wave-uniform), lane offset in bytes.
 template <int THREADS, int CA, int CB, int I, bool WT = false>
 struct CopyFast {
     // step I of ceil((CA+CB)/THREADS): load chunk q = tid + I*THREADS, recurse (so every LDS read is
@@ -795,7 +790,9 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                 if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
             });
             cxy[k] = sl[k].pxy + dxy; cz[k] = sl[k].pz + dz;
-            // the morphed positions are kept (sorted order) for later calls that declare the rates unchanged
+            // the morphed positions are kept (sorted order) for later calls that declare the rates unchanged; the record of
+            // which rates `morphed` belongs to (morph_apply_kernel) no longer holds
+            if (k == 0 && grp == 0 && tile == 0 && tid == 0 && p.morphed && p.morph_seen) p.morph_seen[kSeenValid] = 0u;
             if (grp == 0 && p.morphed && sl[k].act) {
                 float *mo = p.morphed + (size_t(v0) + uint32_t(tid) + uint32_t(k) * THREADS) * 3;
                 mo[0] = cxy[k].x; mo[1] = cxy[k].y; mo[2] = cz[k];
@@ -983,35 +980,63 @@ template <bool F16, bool FUSED_FLATTEN>
 __global__ __launch_bounds__(kThreads) void morph_apply_kernel(const DeformParams p,
                                                                const FlattenParams f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t last_block;
     const float *wsl = p.wslot;
+    bool walk = true;
     if constexpr (FUSED_FLATTEN) {
-        float *wl = reinterpret_cast<float *>(smem);
-        for (uint32_t s = threadIdx.x; s <= f.ns; s += kThreads)     // slot ns = padding, weight 0
-            wl[s] = s < f.ns ? slot_weight(f.rates, f.slot_top, f.chain_off, f.chain_rate, s) : 0.f;
-        __syncthreads();
-        wsl = wl;
+        // vertex_images_ depends on morph_rates_ only (poser_impl.inl:362-386): when this call's rates are, bit for bit, the ones
+        // `morphed` was last computed from (f.seen, written by the last workgroup of that launch), there is nothing to do.
+        if (f.seen) {
+            bool same = f.seen[kSeenValid] == 1u;
+            for (uint32_t m = threadIdx.x; m < f.nm; m += kThreads) same = same && __float_as_uint(f.rates[m]) == f.seen[kSeenRates + m];
+            walk = __syncthreads_and(same) == 0;
+        }
+        if (walk) {
+            float *wl = reinterpret_cast<float *>(smem);
+            for (uint32_t s = threadIdx.x; s <= f.ns; s += kThreads)     // slot ns = padding, weight 0
+                wl[s] = s < f.ns ? slot_weight(f.rates, f.slot_top, f.chain_off, f.chain_rate, s) : 0.f;
+            __syncthreads();
+            wsl = wl;
+        }
     }
     const size_t gs = size_t(blockIdx.x) * kThreads + threadIdx.x;
-    if (gs >= p.nv) return;
-    float bx, by, bz;
-    if constexpr (F16) {
-        const uint2 r = reinterpret_cast<const uint2 *>(p.spos)[gs];
-        bx = h2f(r.x & 0xffffu); by = h2f(r.x >> 16); bz = h2f(r.y & 0xffffu);
-    } else {
-        const float *sp = reinterpret_cast<const float *>(p.spos) + gs * 3;
-        bx = sp[0]; by = sp[1]; bz = sp[2];
+    if (walk && gs < p.nv) {
+        float bx, by, bz;
+        if constexpr (F16) {
+            const uint2 r = reinterpret_cast<const uint2 *>(p.spos)[gs];
+            bx = h2f(r.x & 0xffffu); by = h2f(r.x >> 16); bz = h2f(r.y & 0xffffu);
+        } else {
+            const float *sp = reinterpret_cast<const float *>(p.spos) + gs * 3;
+            bx = sp[0]; by = sp[1]; bz = sp[2];
+        }
+        v2f dxy = v2f{0.f, 0.f};
+        float dz = 0.f;
+        const uint2 sl2 = p.ell[gs >> 6];
+        // a thread of this pass has nothing else in its registers: 16 entries in flight cover most rows in one round trip
+        for_row<F16, 16>(p.entries, sl2.x + uint32_t(gs & 63), sl2.y, [&](float ox, float oy, float oz, uint32_t slot) {
+            const float w = wsl[slot];
+            if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
+        });
+        p.morphed[gs * 3] = bx + dxy.x;
+        p.morphed[gs * 3 + 1] = by + dxy.y;
+        p.morphed[gs * 3 + 2] = bz + dz;
     }
-    v2f dxy = v2f{0.f, 0.f};
-    float dz = 0.f;
-    const uint2 sl2 = p.ell[gs >> 6];
-    // a thread of this pass has nothing else in its registers: 16 entries in flight cover most rows in one round trip
-    for_row<F16, 16>(p.entries, sl2.x + uint32_t(gs & 63), sl2.y, [&](float ox, float oy, float oz, uint32_t slot) {
-        const float w = wsl[slot];
-        if (!(w < kMorphEps)) { dxy = dxy + v2f{ox, oy} * w; dz = dz + oz * w; }
-    });
-    p.morphed[gs * 3] = bx + dxy.x;
-    p.morphed[gs * 3 + 1] = by + dxy.y;
-    p.morphed[gs * 3 + 2] = bz + dz;
+    if constexpr (FUSED_FLATTEN) {
+        // The workgroup that finishes LAST records the rates (every other one has compared by then: its ticket comes after its
+        // reads), so no workgroup ever compares against a half-written record; the next launch on the stream sees it whole.
+        if (f.seen) {
+            if (threadIdx.x == 0) last_block = atomicAdd(&f.seen[kSeenTicket], 1u) == gridDim.x - 1 ? 1u : 0u;
+            __syncthreads();
+            if (last_block) {
+                for (uint32_t m = threadIdx.x; m < f.nm; m += kThreads) f.seen[kSeenRates + m] = __float_as_uint(f.rates[m]);
+                if (threadIdx.x == 0) {
+                    f.seen[kSeenValid] = 1u;
+                    f.seen[kSeenTicket] = 0u;
+                    f.seen[walk ? kSeenWalks : kSeenSkips] += 1u;
+                }
+            }
+        }
+    }
 }
 
 #ifndef MMDX_FAST_MATH
@@ -1121,7 +1146,7 @@ KernelFn pick_t(int layout, int morph, bool f16) {
 // wt = write-through stores (CopyFast): instantiated where it was measured to pay -- the SoA f32 crowd kernels (256 threads, no
 // morphs or shared morphs, original vertex order); every other shape keeps its nt stores whatever the hint says.
 KernelFn pick(int threads, int layout, int morph, bool f16, bool tile, bool wt = false) {
-    if (wt && threads == 256 && layout == MMDX_OUT_SOA && !f16 && !tile && (morph == kMorphNone || morph == kMorphShared))
+    if (wt && deform_has_write_through(threads, layout, morph, f16, tile))
         return morph == kMorphNone ? deform_kernel<256, MMDX_OUT_SOA, kMorphNone, false, false, true>
                                    : deform_kernel<256, MMDX_OUT_SOA, kMorphShared, false, false, true>;
 #if MMDX_TILE >= 512

@@ -62,8 +62,15 @@ struct DeformParams {
     uint32_t interleave;         // crowd modes: instance = g*ngroups + grp instead of grp*group + g
     uint32_t tile_order;         // MMDX_CREATE_TILE_ORDER: outputs in the engine's vertex order (tile-local class sort), stored straight
                                  // from registers -- no LDS image, no per-instance barrier
-    uint32_t write_through;      // host-side hint (launch_deform): the write-through flavour of the copy-out, where one exists
+    uint32_t write_through;      // launch the write-through flavour of the copy-out (api.cpp sets it only where deform_has_write_through())
+    uint32_t *morph_seen;        // kMorphFused1 crowds: the handle's RatesSeen record; a launch that overwrites `morphed` clears its
+                                 // valid word (the record no longer describes what `morphed` holds)
 };
+
+// Device-side record of the morph rates the `morphed` buffer of a handle was last computed from (shared morph pass of a crowd):
+// morph_apply_kernel compares the call's rates with it, bit for bit, and skips its walk when they are equal -- the automatic form of
+// MMDX_MORPH_UNCHANGED for rates that live in device memory, where the host cannot look.  u32 words:
+enum : uint32_t { kSeenValid = 0, kSeenTicket = 1, kSeenWalks = 2, kSeenSkips = 3, kSeenRates = 4 };   // then NM rate bit patterns
 
 struct FlattenParams {
     const float *rates;          // [NIw][NM] device
@@ -72,11 +79,18 @@ struct FlattenParams {
     float *out;
     uint32_t nm, ns, niw;
     uint32_t quad;               // 1: write float4 [ceil(NIw/4)][NS] instance quads (pad lanes = 0)
+    uint32_t *seen;              // morph_apply with the flatten fused in: the handle's RatesSeen record (nullptr: always walk)
 };
 
 // Bytes of dynamic LDS the deform kernel needs for (layout, morph mode, group).
 size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint32_t max_tile_bones, uint32_t ns,
                         uint32_t *stage_off, uint32_t *w_off, bool tile_order = false);
+
+// Does this launch shape exist in the write-through store flavour?  (Measured to pay on the SoA f32 crowd kernels only: 256 threads,
+// no morphs or shared morphs, original vertex order.)  api.cpp asks before it sets DeformParams::write_through, pick() asserts it.
+constexpr bool deform_has_write_through(int threads, int layout, int morph, bool f16, bool tile_order) {
+    return threads == 256 && layout == 0 /* MMDX_OUT_SOA */ && !f16 && !tile_order && (morph == kMorphNone || morph == kMorphShared);
+}
 
 hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream);

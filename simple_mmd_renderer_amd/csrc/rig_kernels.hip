@@ -8,6 +8,8 @@
 #include "rig.hpp"
 #include "rig_kernels.hpp"
 
+#include <atomic>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -957,10 +959,17 @@ hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream) {
     static const int dense_env = env_int("MMDX_SOLVE_DENSE", -1);             // A/B: 0 never, 1 whenever it fits
     bool dense = !p.nested && 2 * (lds + 1024) <= 160 * 1024;
     if (dense && dense_env != 1) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            cus = 256;
+        // CU count of the current device, asked once per device and process (two runtime calls per IK launch otherwise)
+        static std::atomic<int> cu_count[16] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        int cus = dev >= 0 && dev < 16 ? cu_count[dev].load(std::memory_order_relaxed) : 0;
+        if (cus == 0) {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+                (void)hipGetLastError();
+                cus = 256;
+            }
+            if (dev >= 0 && dev < 16) cu_count[dev].store(cus, std::memory_order_relaxed);
         }
         dense = dense_env != 0 && wgs > uint32_t(cus);
     }

@@ -263,10 +263,11 @@ class DeformModel:
 
     def alloc_outputs(self, layout: int, ni: int, max_tries: int = 16):
         """The crowd's output arrays through mmdx_crowd_output_alloc (placement-aware on MI355X).
-        Returns (a, b or None, info dict)."""
+        Returns (a, b or None, info dict); info["store_flags"] is the MMDX_OUT_STORES_* hint to OR into the flags of the crowd
+        calls that write these arrays (the library itself remembers nothing about them)."""
         class _Info(C.Structure):
             _fields_ = [("struct_size", C.c_uint32), ("tries", C.c_uint32), ("probed", C.c_uint32),
-                        ("store_GBs", C.c_float), ("fill_GBs", C.c_float)]
+                        ("store_GBs", C.c_float), ("fill_GBs", C.c_float), ("store_flags", C.c_uint32)]
         info = _Info()
         info.struct_size = C.sizeof(_Info)
         pa, pb = C.c_void_p(), C.c_void_p()
@@ -276,7 +277,7 @@ class DeformModel:
         a = DeviceBuffer.adopt(pa.value, sa)
         b = DeviceBuffer.adopt(pb.value, sb) if pb.value else None
         return a, b, {"tries": info.tries, "probed": bool(info.probed), "store_GBs": info.store_GBs,
-                      "fill_GBs": info.fill_GBs}
+                      "fill_GBs": info.fill_GBs, "store_flags": int(info.store_flags)}
 
     def deform_batched_raw(self, ni: int, weights_ptr, palettes_ptr, out_a_ptr, out_b_ptr, layout: int,
                            flags: int, pos_scale: float = 1.0) -> None:
@@ -314,8 +315,15 @@ class DeformModel:
     def sync(self) -> None:
         api.check(api.lib().mmdx_sync(self.h))
 
+    def morph_pass_stats(self) -> Tuple[int, int, int]:
+        """(launches that walked the morph table, launches that found the rates unchanged on the device and skipped the walk,
+        calls whose host-side comparison skipped the launch) of this model's shared morph passes."""
+        w, d, h = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        api.check(api.lib().mmdx_debug_morph_pass_stats(self.h, C.byref(w), C.byref(d), C.byref(h)))
+        return w.value, d.value, h.value
+
     def last_store_policy(self) -> str:
-        """Store flavour the last crowd call asked of its kernel: 'nt' (cached, non-temporal) or 'sc1 nt' (write-through)."""
+        """Store flavour the kernel of the last crowd call ran with: 'nt' (cached, non-temporal) or 'sc1 nt' (write-through)."""
         wt = C.c_int32(0)
         api.check(api.lib().mmdx_debug_last_store_policy(self.h, C.byref(wt)))
         return "sc1 nt" if wt.value else "nt"

@@ -34,8 +34,8 @@ def test_unknown_create_flags_are_rejected(hip_lib):
     assert st == 1 and b"unknown bits" in hip_lib.mmdx_last_error_string()
 
 
-def test_abi_version_is_2(hip_lib):
-    assert hip_lib.mmdx_abi_version() == api.ABI_VERSION == 2
+def test_abi_version_is_3(hip_lib):
+    assert hip_lib.mmdx_abi_version() == api.ABI_VERSION == 3
 
 
 # ---- GPU -------------------------------------------------------------------------------------------------------------

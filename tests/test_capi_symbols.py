@@ -24,7 +24,7 @@ def test_boundary_header_carries_no_bench_or_debug_entry_points():
     assert not [s for s in syms if s.startswith(("mmdx_bench_", "mmdx_debug_", "mmdx_timer_", "mmdx_profile_"))]
     assert set(declared_symbols((BENCH_HEADER,))) == {
         "mmdx_timer_start", "mmdx_timer_stop", "mmdx_profile_enable", "mmdx_profile_collect", "mmdx_debug_reload_env",
-        "mmdx_debug_last_store_policy",
+        "mmdx_debug_last_store_policy", "mmdx_debug_morph_pass_stats", "mmdx_build_source_sha",
         "mmdx_bench_copy", "mmdx_bench_fill", "mmdx_bench_store_pattern"}
 
 
@@ -56,8 +56,18 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_capi.ModelInfo) == 80   # 13 u32, pad to 8, u64, 3 u32, tail pad
 
 
+def test_library_is_stamped_with_the_source_revision_of_this_tree(hip_lib):
+    """The binary proves which sources it was built from (mmdx_build_source_sha): the stamp read through the ABI, the stamp
+    found in the file's bytes and the hash of the tree's sources are one and the same; build() rebuilds on content, not mtime."""
+    from simple_mmd_renderer_amd import build
+    got = _capi.check_library_matches_tree()
+    assert got["library_source_sha"] == got["tree_source_sha"] == build.library_sha() == build.source_sha()
+    assert len(got["library_source_sha"]) == 40
+    assert build.up_to_date()
+
+
 def test_abi_version_and_error_string(hip_lib):
-    assert hip_lib.mmdx_abi_version() == 2
+    assert hip_lib.mmdx_abi_version() == 3
     st = hip_lib.mmdx_model_create(None, None)
     assert st == 1
     assert b"NULL" in hip_lib.mmdx_last_error_string()

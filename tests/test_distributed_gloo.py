@@ -86,6 +86,34 @@ def test_bench_launches_its_own_ranks_dry(world):
     assert line["ranges"] == [[10 * k, 10 * (k + 1)] for k in range(world)]
 
 
+@pytest.mark.parametrize("launcher", ["own", "torchrun"])
+def test_bench_world_8_dry_run_is_config4s_sharding(launcher):
+    """BASELINE config 4 as the driver will start it -- `bench.py --gpus 8`, by itself or under torch.distributed.run with
+    --nproc-per-node 8 -- cannot fail in the launcher: eight ranks rendezvous (gloo, 127.0.0.1), rank k owns instances
+    [1024 k, 1024 (k + 1)) of the 8 192-instance crowd, ONE JSON line comes back.  --dry-run stops before the GPU work."""
+    import json as _json
+    import socket
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run"]
+    if launcher == "own":
+        cmd = [sys.executable] + tail
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = _json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["instances"] == 8192 and line["scaling"] == "weak"
+    assert line["ranges"] == [[1024 * k, 1024 * (k + 1)] for k in range(8)]
+    assert line["steps"] == 20 and line["warmup"] == 5
+
+
 def test_bench_launcher_reports_a_failing_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "x"],

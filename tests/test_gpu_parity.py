@@ -621,8 +621,9 @@ def test_config4_every_ranks_shard_full_size_on_one_device(oracle):
 
 def test_crowd_store_policy_hints_and_defaults(oracle):
     """The store flavour of the crowd kernel's copy-out (mmdx.h MMDX_OUT_STORES_*): write-through (`sc1 nt`) or cached
-    non-temporal (`nt`) stores -- same results, bit for bit, whichever is chosen, and the default follows what the library knows
-    about the arrays: from mmdx_crowd_output_alloc by the probe's verdict, unknown arrays write-through, small crowds never."""
+    non-temporal (`nt`) stores -- same results, bit for bit, whichever is chosen.  The decision is made from the call alone (no
+    table of addresses behind the boundary): the caller's hint -- mmdx_crowd_output_alloc hands out the probe's verdict as one --
+    else write-through for outputs of >= 512 MB, cached for smaller ones; and only kernels that have the flavour report it."""
     from simple_mmd_renderer_amd.crowd import crowd_frames
     m = synth.make_config("config3_crowd")
     ni = 1024
@@ -636,8 +637,8 @@ def test_crowd_store_policy_hints_and_defaults(oracle):
     want = {i: oracle.skin(m, pals[i], vimg, skin) for i in sample}
     with DeformModel(m) as dm:
         d_w, d_pal = DeviceBuffer.from_numpy(rates), DeviceBuffer.from_numpy(pals)
-        d_a, d_b, pl = dm.alloc_outputs(api.OUT_SOA, ni, 4)                 # probed: the registry knows these arrays
-        p_a, p_b = DeviceBuffer(ni * row), DeviceBuffer(ni * row)           # plain: it does not
+        d_a, d_b, pl = dm.alloc_outputs(api.OUT_SOA, ni, 4)                 # probed: the verdict comes back as a flag
+        p_a, p_b = DeviceBuffer(ni * row), DeviceBuffer(ni * row)           # plain
 
         def run(a, b, flags, n=ni):
             a.memset(0xFF); b.memset(0xFF)
@@ -657,8 +658,16 @@ def test_crowd_store_policy_hints_and_defaults(oracle):
         assert run(p_a, p_b, base) == "sc1 nt"                               # nothing known about these arrays
         check(p_a, p_b, "default, unknown arrays")
         fast = pl["store_GBs"] >= 0.92 * pl["fill_GBs"]
-        assert run(d_a, d_b, base) == ("nt" if fast else "sc1 nt")          # the probe's verdict
-        check(d_a, d_b, "default, probed arrays")
+        assert pl["store_flags"] == (api.OUT_STORES_CACHED if fast else api.OUT_STORES_WRITE_THROUGH)
+        assert run(d_a, d_b, base | pl["store_flags"]) == ("nt" if fast else "sc1 nt")   # the probe's verdict, carried by the caller
+        check(d_a, d_b, "probed arrays, verdict passed on")
+        assert run(d_a, d_b, base) == "sc1 nt"                               # ... and nothing is remembered without it
+        # free and re-allocate: whatever lands on the old addresses inherits nothing (the library keeps no record of arrays)
+        old = (d_a.ptr, d_b.ptr)
+        d_a.free(); d_b.free()
+        d_a, d_b = DeviceBuffer(ni * row), DeviceBuffer(ni * row)
+        assert run(d_a, d_b, base) == "sc1 nt", f"re-allocated arrays (old {old}, new {(d_a.ptr, d_b.ptr)})"
+        check(d_a, d_b, "default, re-allocated arrays")
         assert run(d_a, d_b, base | api.MORPH_UNCHANGED | api.OUT_STORES_WRITE_THROUGH) == "sc1 nt"   # the no-morph-pass kernel too
         check(d_a, d_b, "write-through, morph pass skipped")
         assert run(p_a, p_b, base, n=64) == "nt"                             # 77 MB of output: stays cached
@@ -669,6 +678,7 @@ def test_crowd_store_policy_hints_and_defaults(oracle):
         v32 = DeviceBuffer(ni * m.nv * 32)
         dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, v32.ptr, None, api.OUT_VERTEX32, base | api.OUT_STORES_WRITE_THROUGH, 0.1)
         dm.sync()
+        assert dm.last_store_policy() == "nt"                                # what RAN, not what was asked for
         for i in sample[:3]:
             gu.assert_bits_equal(v32.download((m.nv, 8), np.float32, offset=i * m.nv * 32),
                                  oracle.repack32(m, want[i][0], want[i][1], 0.1), f"v32 with the hint: inst {i}")

@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
 
-KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_INTERLEAVE", "MMDX_SHARED_FUSED", "MMDX_EXPERIMENT_DIRECT")
+KNOBS = ("MMDX_GROUP", "MMDX_THREADS", "MMDX_LDS_TARGET", "MMDX_INTERLEAVE", "MMDX_SHARED_FUSED", "MMDX_EXPERIMENT_DIRECT", "MMDX_STORE_WT",
+         "MMDX_MORPH_AUTOSKIP")
 
 
 def main():
@@ -38,6 +39,8 @@ def main():
     d_a, d_b, placement = dm.alloc_outputs(layout, ni, int(os.environ.get("AB_TRIES", "24")))   # AB_TRIES=1: whatever hipMalloc hands out first
     print("output placement:", placement, flush=True)
     flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | api.WEIGHTS_SHARED
+    if "MMDX_STORE_WT" not in " ".join(sys.argv[1:]):
+        flags |= placement.get("store_flags", 0)       # the probe's verdict travels with the call (unless the A/B is about it)
     dense = os.environ.get("AB_DENSE") == "1"
     dm.profile_enable(not dense)
     res = [[] for _ in cfgs]

@@ -27,7 +27,7 @@ def main():
     dms = [DeformModel(m, **kw) for _, kw in modes]
     d_a, d_b, pl = dms[0].alloc_outputs(api.OUT_SOA, ni, int(os.environ.get("AB_TRIES", "64")))
     print("output placement:", pl, flush=True)
-    base = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+    base = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | pl.get("store_flags", 0)
     res = {(n, w): [] for n, _ in modes for w in ("crowd", "per-instance")}
     for r in range(rounds + 2):
         for (name, _), dm in zip(modes, dms):
