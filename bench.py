@@ -514,6 +514,21 @@ def fused_pmc_traffic(out):
                        "pmc_frac_of_8TBs": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "pmc_traffic_over_algorithmic": traffic / (out[k]["algorithmic_GBs"] * 1e9 * ms * 1e-3),
                        "pmc_source": src})
+        # Which roof binds: these kernels are bit-exact, i.e. unfused multiply-adds, and their instruction stream is as much a
+        # floor as their bytes.  Floors from the same counter passes: HBM = algorithmic bytes at the 8 TB/s peak; VALU = vector
+        # wave-instructions x 4 cycles (a wave64 instruction occupies its SIMD-32 for 2 passes x 2: packed f32 math, which is most
+        # of the stream) on 1024 SIMDs at 2.4 GHz = 614.4 G wave-instructions/s; LDS = cycles the LDS arrays were busy, per CU.
+        sq = {r["counter"]: float(r["mean"]) for r in rows if "deform_kernel" in r["kernel"] and r["grid_threads"] == grid
+              and r["counter"] in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE")}
+        if len(sq) == 2:
+            alg_bytes = out[k]["algorithmic_GBs"] * 1e9 * ms * 1e-3
+            floors = {"hbm": alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e6,
+                      "valu": sq["SQ_INSTS_VALU"] / 614.4e9 * 1e6,
+                      "lds": sq["SQ_LDS_IDX_ACTIVE"] / 256 / 2.4e9 * 1e6}
+            bound = max(floors, key=floors.get)
+            out[k].update({"floors_us": {n: round(t, 2) for n, t in floors.items()}, "bound": bound,
+                           "frac_of_binding_floor": floors[bound] / (ms * 1e3),
+                           "valu_wave_instructions": sq["SQ_INSTS_VALU"]})
 
 
 def time_calls(dm, fn, iters, warm=3, settle_ms=60.0):

@@ -248,7 +248,7 @@ LaunchOverrides mmdx::read_launch_overrides() {
     return {env_int("MMDX_INTERLEAVE", 1), env_int("MMDX_THREADS", 0), env_int("MMDX_LDS_TARGET", 0),
             env_int("MMDX_GROUP", 0), env_int("MMDX_PLACEMENT_LOG", 0), env_int("MMDX_PLACEMENT_PARK", 0),
             env_int("MMDX_FRAME_KERNEL", 1), env_int("MMDX_FRAME_THREADS", 256), env_int("MMDX_SHARED_FUSED", 1),
-            env_int("MMDX_STORE_WT", -1), env_int("MMDX_MORPH_AUTOSKIP", 1)};
+            env_int("MMDX_STORE_WT", -1), env_int("MMDX_MORPH_AUTOSKIP", 1), env_int("MMDX_FUSED_PACK", 0), env_int("MMDX_STAGGER", 0)};
 }
 LaunchOverrides &mmdx::launch_overrides() {
     static LaunchOverrides o = read_launch_overrides();
@@ -746,11 +746,46 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (forced > 0) group = std::max(uint32_t(forced) / gmin * gmin, gmin);
     }
     dp.group = group;
-    const size_t lds = deform_lds_bytes(threads, layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off, dp.tile_order != 0);
+    // Per-instance morph weights, second shape (kernels.hip pack_kernel), OPT-IN (MMDX_FUSED_PACK=1): packs of 4 instances, 80 registers,
+    // three 8-wave workgroups per CU while a workgroup's LDS stays under a third of the CU's.  It runs at 5.7 waves per SIMD where
+    // deform_kernel<512, ., kMorphFused4> runs at 3.8 -- and loses (config 3' 372-382 us against 335-348; profiles/r04/fused_pack_*):
+    // the walk and the skinning of one CU do not overlap in either kernel (walk alone 132 us + skinning alone 254 us), and packs of 4
+    // walk the table twice as often as packs of 8.  Kept for the A/B, not the default.  Two-array layouts in original vertex order.
+    // The group: as many instances (multiple of 4, up to 16) as keep three workgroups on a CU, else as fit two.
+    bool pack = morph == kMorphFused4 && ov.fused_pack != 0 && kTileVerts == 512 && !dp.tile_order && layout != MMDX_OUT_VERTEX32 && !ov.threads;
+    size_t lds = 0;
+    if (pack) {
+        uint32_t so, wo, mo;
+        const size_t third = (160 * 1024) / 3 - 64, half = 80 * 1024 - 64;
+        uint32_t g = 0;
+        for (uint32_t c = 16; c >= 4 && !g; c -= 4)
+            if (pack_lds_bytes(c, p.max_tile_bones, p.ns, &so, &wo, &mo) <= third) g = c;
+        for (uint32_t c = 16; c >= 4 && !g; c -= 4)
+            if (pack_lds_bytes(c, p.max_tile_bones, p.ns, &so, &wo, &mo) <= half) g = c;
+        if (!g && pack_lds_bytes(4, p.max_tile_bones, p.ns, &so, &wo, &mo) <= 160 * 1024) g = 4;
+        if (ov.group > 0) g = std::max(uint32_t(ov.group) / 4 * 4, 4u);
+        if (g) {
+            g = std::min(g, (ni + 3) / 4 * 4);
+            while (g > 4 && uint64_t(p.ntiles) * ((ni + g - 1) / g) < 1536) g -= 4;     // keep 256 CUs x 3 workgroups busy twice over
+            dp.group = g;
+            lds = pack_lds_bytes(g, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off, &dp.mp_off);
+            if (lds > 160 * 1024) pack = false;
+        } else {
+            pack = false;
+        }
+    }
+    if (!pack) {
+        dp.group = group;
+        lds = deform_lds_bytes(threads, layout, morph, group, p.max_tile_bones, p.ns, &dp.stage_off, &dp.w_off, dp.tile_order != 0);
+    }
     if (lds > 160 * 1024)
         return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(lds) + " bytes of LDS (> 160 KiB): "
                                           "too many distinct bones in one vertex tile / too many morph slots");
 
+    if (morph == kMorphFused4) {
+        dp.stagger = uint32_t(std::max(ov.stagger, 0));
+        dp.slots_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(uint32_t(160 * 1024 / std::max<size_t>(lds, 1)), pack ? 3u : 2u));
+    }
     if (pev) HIP_TRY(hipEventRecord(pev[0], st));
     // One frame of one model into device memory: the latency-ordered kernel (parts of tiles on every CU, direct stores).
     // Outputs in mapped host memory keep the tile kernel: its 16-byte coalesced stores are what crosses PCIe well.
@@ -764,6 +799,8 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
         if (flds > 160 * 1024)
             return fail(MMDX_ERR_UNSUPPORTED, "tile needs " + std::to_string(flds) + " bytes of LDS (> 160 KiB)");
         HIP_TRY((fast ? launch_frame_fast : launch_frame)(ov.frame_threads, int(layout), morph, p.f16, fp, p.ntiles, flds, st));
+    } else if (pack) {
+        HIP_TRY((fast ? launch_pack_fast : launch_pack)(int(layout), p.f16, dp, p.ntiles, lds, st));
     } else {
         HIP_TRY((fast ? launch_deform_fast : launch_deform)(threads, int(layout), morph, p.f16, dp, p.ntiles, lds, st));
     }

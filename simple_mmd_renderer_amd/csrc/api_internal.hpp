@@ -60,6 +60,9 @@ struct LaunchOverrides {
                         // 1 up to 8 instances (default), 2 always (A/B, tests)
     int store_wt;       // MMDX_STORE_WT: 0 / 1 force cached / write-through stores where the caller gave no hint (A/B); -1 default
     int morph_autoskip; // MMDX_MORPH_AUTOSKIP: 0 turns the automatic "shared rates unchanged" detection off (A/B); 1 default
+    int fused_pack;     // MMDX_FUSED_PACK: 0 = per-instance morph weights run deform_kernel<512, ., kMorphFused4> (default),
+                        // 1 = pack_kernel (round 4's higher-occupancy shape: measured slower, kept for the A/B)
+    int stagger;        // MMDX_STAGGER: start offset between the workgroups of a CU, in units of 64 cycles per residency slot (A/B)
 };
 LaunchOverrides read_launch_overrides();
 LaunchOverrides &launch_overrides();

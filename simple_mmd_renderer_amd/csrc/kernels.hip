@@ -23,6 +23,11 @@
 #include "kernels.hpp"
 
 #include <type_traits>
+#ifdef PK_STAMPS
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#endif
 
 // MMDX_FAST_MATH (kernels_fast.hip includes this file with it defined): the SAME kernels with multiply-add contraction allowed
 // (v_fma_f32 / v_pk_fma_f32) for models created with MMDX_CREATE_FAST_MATH -- results within a stated tolerance of the
@@ -436,17 +441,21 @@ __device__ __forceinline__ void load_slot(const DeformParams &p, const TileHdr &
 // matrix row: sixteen 64-byte pieces); the bone id is wave-uniform, so it comes through the scalar cache and the
 // palette loads do not wait for a vector load of the bone list first -- one dependent round trip less in a
 // set-up phase that runs while the CU's memory pipeline is full of other workgroups' stores.
+// `qstep` != 0: the group is made of instance QUADS qstep quads apart (pack_kernel's interleaved mapping): group instance g is
+// instance inst0 + (g >> 2) * 4 * qstep + (g & 3); instances past the crowd's end are left out.
 template <int THREADS>
 __device__ __forceinline__ void stage_palettes(const DeformParams &p, const TileHdr &th, float4 *pal, uint32_t inst0,
-                                               uint32_t istep, uint32_t count, int tid) {
+                                               uint32_t istep, uint32_t count, int tid, uint32_t qstep = 0u) {
     const uint32_t nbt = th.nbt;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(uint32_t(tid) >> 6), lane = uint32_t(tid) & 63u;
     const uint32_t gl = lane >> 2, r = lane & 3u;
     const uint32_t *bones = p.bone_list + th.bone_off;
     for (uint32_t g0 = 0; g0 < count; g0 += 16) {
         const uint32_t g = g0 + gl;
-        const bool on = g < count;
-        const float *src = p.palettes + size_t(inst0 + (on ? g : 0u) * istep) * p.nb * 16 + r * 4;
+        uint32_t inst = inst0 + (g < count ? g : 0u) * istep;
+        if (qstep) inst = inst0 + (g >> 2) * 4u * qstep + (g & 3u);
+        const bool on = g < count && inst < p.ni;
+        const float *src = p.palettes + size_t(on ? inst : inst0) * p.nb * 16 + r * 4;
         float *dst = reinterpret_cast<float *>(pal + size_t(g) * p.pal_stride);
 #pragma unroll 4
         for (uint32_t lb = wave; lb < nbt; lb += THREADS / 64) {
@@ -697,6 +706,17 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
     }
 }
 
+// Workgroups of one CU that run the same program start together and stay in step: all in their walk (vector-memory loads), then
+// all in their stores.  First-round workgroups are therefore started out of phase: residency slot k of a CU (blocks are dealt
+// round-robin over the 8 XCDs, then over an XCD's 32 CUs: observed, speed only) sleeps k * stagger * 64 cycles first.  Later
+// workgroups inherit the offset of the one whose place they take.
+__device__ __forceinline__ void stagger_start(const DeformParams &p) {
+    if (p.stagger == 0u || p.slots_per_cu < 2u) return;
+    const uint32_t round = blockIdx.x >> 8;                 // 8 XCDs x 32 CUs
+    if (round >= p.slots_per_cu) return;
+    for (uint32_t k = 0; k < round * p.stagger; k += 100) __builtin_amdgcn_s_sleep(100);
+}
+
 // ---- the deformation kernel ----------------------------------------------------------------------
 // THREADS = 512: one sorted slot per lane, 8 waves per workgroup; THREADS = 256: two slots per lane.
 template <int THREADS, int LAYOUT, int MORPH, bool F16, bool TILE, bool WT = false>
@@ -706,6 +726,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     const int tid = threadIdx.x;
     uint32_t tile, grp;
     if (!map_workgroup(p, tile, grp)) return;       // padding workgroup
+    if constexpr (MORPH == kMorphFused4) stagger_start(p);
     const TileHdr &th = p.tiles[tile];
     const uint32_t v0 = th.v0, nvt = th.nv;
     // Instances of this workgroup.  Blocked: grp*group + g.  Interleaved (crowd modes): g*ngroups + grp,
@@ -830,7 +851,11 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                         w[4] = b4.x; w[5] = b4.y; w[6] = b4.z; w[7] = b4.w;
                     }
                 };
+#ifdef FUSED4_SKIP_WALK       // timing diagnostic only (wrong results): this kernel without its walk
+                if (false) {
+#else
                 if (p.finite_offsets) {
+#endif
                     // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
                     // the image bit-for-bit unchanged: the skip needs no branch.
@@ -854,6 +879,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
 #endif
                     });
                 } else {
+#ifndef FUSED4_SKIP_WALK
                     for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
@@ -862,6 +888,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                         for (int j = 0; j < kPack; ++j)
                             if (!(w[j] < kMorphEps)) { dxy[k][j] += oxy * w[j]; dz[k][j] += oz * w[j]; }
                     });
+#endif
                 }
             }
             const bool more = g0 + kPack < gcount;
@@ -903,6 +930,327 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         if (all_fast) instances(std::true_type{});
         else instances(std::false_type{});
     }
+}
+
+// ---- per-instance morph weights, second shape (round 4): packs of 4 instances, walk and skinning in SEPARATE phases -------------
+// deform_kernel<512, ., kMorphFused4> holds, at the same time, the walk's accumulators for 8 instances, the entries in flight, the
+// vertex's skin data and the blend's matrices: 126 VGPRs, two 8-wave workgroups per CU, and its counters say it waits (VALU issue
+// 59 %, LDS 50 % of the cycles, waves parked 53 % of their life: profiles/r03/fused_gather_pmc.csv).  This kernel is laid out from
+// the register budget down -- 80 VGPRs, three workgroups per CU, six waves per SIMD:
+//   * a PACK is 4 instances (one float4 of slot weights per table entry): 12 accumulator registers;
+//   * WALK phase: the row is consumed through a rolling window of 4 entries in flight (no second register set, no copies);
+//     at its end `coordinate = base + image` (poser_impl.inl:407) of instances 1..3 goes to LDS (`mp`, component-major: every
+//     access is lane-consecutive), instance 0's stays in registers -- the accumulators are dead before the first matrix is read;
+//   * SKIN phase, per instance: the vertex's coordinate comes back from LDS (the thread's own words: no barrier), blend + transform
+//     as in deform_kernel, results scattered to the output images, ONE barrier, coalesced 16-byte copy-out.  The position image of
+//     instance j is the `mp` region of instance j (its coordinates were read before the previous instance's barrier: everybody is
+//     done with them), the normal image is double buffered -- 48.6 KB of LDS for 8 instances of the 50k model.
+// Same operations in the same order as the reference (and as deform_kernel): bit-identical results.
+constexpr int kPkThreads = 512;
+constexpr uint32_t kPkPack = 4;
+constexpr uint32_t kPkRegion = kSoaImgBytes;          // one `mp` region: 512 x 3 f32 coordinates, or a position image (f32: 6160 B, f16: 3088 B)
+static_assert(kPkRegion >= kTileVerts * 12 && kPkRegion >= kP16ImgBytes && kPkRegion % 16 == 0, "mp region");
+
+// The vertex's static data as the pack kernel keeps it across its loops: 14 registers (load_slot's Slot: 21).
+struct PackSlot {
+    v2f pxy, nxy;
+    float pz, nz;
+    float w0, w1, w2, w3;
+    uint32_t b01, b23;        // palette entries of the vertex's bones (float4 index inside one instance's palette), two per register
+    uint32_t meta;            // perm | deform class << 10 | active << 12
+};
+__device__ __forceinline__ PackSlot pack_slot(const Slot &q) {
+    PackSlot s;
+    s.pxy = q.pxy; s.nxy = q.nxy; s.pz = q.pz; s.nz = q.nz;
+    s.w0 = q.w0; s.w1 = q.w1; s.w2 = q.w2; s.w3 = q.w3;
+    s.b01 = q.b0 | (q.b1 << 16); s.b23 = q.b2 | (q.b3 << 16);
+    s.meta = q.perm | (uint32_t(q.cls) << 10) | (q.act ? 1u << 12 : 0u);
+    return s;
+}
+// skin_matrix() from the packed form.  `b01` / `b23` arrive through an opaque copy made inside the instance loop, so that the
+// unpacked indices are not hoisted out of it as four loop-invariant registers.
+__device__ __forceinline__ M12 skin_matrix_packed(uint32_t cls, uint32_t b01, uint32_t b23, float w0, float w1, float w2, float w3,
+                                                  const float4 *P) {
+    M12 m;
+    if (cls == 0) {
+        m = load_m12(P, b01 & 0xffffu);
+    } else if (cls == 1) {
+        const M12 a = load_m12(P, b01 >> 16), e = load_m12(P, b01 & 0xffffu);      // Lerp(S[b1], S[b0])[w]
+        m = blend2(a, e, 1.0f - w0, w0);
+        const bool lo = w0 < kLerpLo, hi = w0 > kLerpHi;
+        if (__builtin_amdgcn_ballot_w64(lo || hi) != 0) {
+            if (lo) m = a;
+            else if (hi) m = e;
+        }
+    } else {
+        {
+            const M12 a = load_m12(P, b01 & 0xffffu), b = load_m12(P, b01 >> 16);
+            m = mul_add(a, w0, b, w1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const M12 c = load_m12(P, b23 & 0xffffu);
+            m = add_mul(m, c, w2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const M12 d = load_m12(P, b23 >> 16);
+            m = add_mul(m, d, w3);
+        }
+    }
+    return m;
+}
+
+#ifndef PK_WAVES
+#define PK_WAVES 6
+#endif
+template <int LAYOUT, bool F16, bool FIN>
+__global__ __launch_bounds__(kPkThreads, PK_WAVES) void pack_kernel(const DeformParams p) {
+    static_assert(LAYOUT == MMDX_OUT_SOA || LAYOUT == MMDX_OUT_SOA_POS16, "two output arrays");
+    static_assert(kTileVerts == 512, "one sorted slot per lane");
+    using Raw = typename RawEntry<F16>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    uint32_t tile, grp;
+    if (!map_workgroup(p, tile, grp)) return;       // padding workgroup
+    const TileHdr &th = p.tiles[tile];
+    const uint32_t v0 = th.v0, nvt = th.nv;
+    // Instances of this workgroup: p.group / 4 quads.  Blocked: consecutive quads.  Interleaved (default): quad k of the workgroup is
+    // quad grp + k * ngroups of the crowd, so that the workgroups running at the same time (neighbouring grp) write neighbouring
+    // instances -- chip-wide the stores then sweep a few contiguous megabytes of each output array, as the crowd kernel's do.
+    const bool ilv = p.interleave != 0;
+    const uint32_t nquads = (p.ni + 3u) >> 2, qstep = ilv ? p.ngroups : 1u;
+    const uint32_t quad0 = ilv ? grp : grp * (p.group >> 2);
+    const uint32_t npacks = quad0 < nquads ? min(p.group >> 2, (nquads - quad0 + qstep - 1) / qstep) : 0u;
+    const uint32_t gcount = npacks * kPkPack;        // group instances incl. the slack of a ragged last quad (never written out)
+    auto first_instance = [&](uint32_t g0) { return (quad0 + (g0 >> 2) * qstep) * 4u; };
+    stagger_start(p);
+    float4 *pal = reinterpret_cast<float4 *>(smem);
+    float4 *wq = reinterpret_cast<float4 *>(smem + p.w_off);
+    unsigned char *mp = smem + p.mp_off;             // kPkPack regions
+    unsigned char *imgB = smem + p.stage_off;        // 2 normal images, BEHIND mp (CopyFast wants image B after image A)
+    const uint32_t wstride = p.ns + 1;
+    auto pack_weight = [&](uint32_t g0, uint32_t i) {
+        return reinterpret_cast<const float4 *>(p.wslot)[size_t(quad0 + (g0 >> 2) * qstep) * wstride + i];
+    };
+    // the lane's row of the morph table: lane `tid & 63` of the wave's slice (lanes past the tile's last vertex walk their
+    // slice's padding: dummy slot, weight 0), padded length wave-uniform -> a scalar.  The row is the same for every pack.
+    const uint2 sl2 = p.ell[(v0 + uint32_t(tid)) >> 6];
+    const uint32_t rbase = sl2.x + (uint32_t(tid) & 63u);
+    const uint32_t rlen = __builtin_amdgcn_readfirstlane(sl2.y);
+    const uint32_t last = rlen ? rlen - 1 : 0u;
+    Raw e[4];                                        // rolling window over the row: four entries in flight
+    auto row_head = [&]() {
+        uint32_t rb = rbase;      // (opaque copies like this one keep loop-invariant address arithmetic and operand splats from being
+        asm volatile("" : "+v"(rb));   // carried around the loops in registers: they are recomputed where they are used)
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) e[i] = rlen ? row_entry<F16>(p.entries, rb, min(i, last)) : Raw{};
+    };
+
+    // set-up: the group's palettes, the first pack's slot weights, the head of the row, the vertex's static data
+    // (one piece after the other: interleaved, their loads in flight would claim more registers than the loops below ever need,
+    // and the allocator would answer by spilling the vertex's skin data for the whole kernel)
+    stage_palettes<kPkThreads>(p, th, pal, quad0 * 4u, 1u, gcount, tid, qstep);
+    __builtin_amdgcn_sched_barrier(0);
+    for (uint32_t i = tid; i < wstride; i += kPkThreads) wq[i] = pack_weight(0, i);
+    __builtin_amdgcn_sched_barrier(0);
+    PackSlot ps;
+    {
+        Slot q;
+        load_slot<LAYOUT, kMorphFused4, F16>(p, th, uint32_t(tid), q);
+        ps = pack_slot(q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    row_head();
+    const bool wreg = wstride <= uint32_t(kPkThreads);
+    constexpr uint32_t kAlignVerts = LAYOUT == MMDX_OUT_SOA_POS16 ? 8u : 4u;
+    const bool al = p.out_aligned != 0;
+    const bool fast = al && nvt == kTileVerts && p.nv % kAlignVerts == 0 && v0 % kAlignVerts == 0;
+    __syncthreads();
+
+#ifdef PK_STAMPS
+    // diagnostic build: where a wave's cycles go (s_memtime, one record of 8 counters per wave; never in the product)
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t;
+#define PK_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define PK_STAMP(k) do { } while (0)
+#endif
+    uint32_t buf = 0;
+    for (uint32_t g0 = 0; g0 < gcount; g0 += kPkPack) {
+        PK_STAMP(0);
+        // ---- WALK: vertex_image = 0; for each applied entry: image = image + offset*rate (poser_impl.inl:340-346), 4 instances --
+        v2f axy[kPkPack], az01 = v2f{0.f, 0.f}, az23 = v2f{0.f, 0.f};
+#pragma unroll
+        for (uint32_t j = 0; j < kPkPack; ++j) axy[j] = v2f{0.f, 0.f};
+        auto apply = [&](const Raw r) {
+            float ox, oy, oz;
+            uint32_t slot;
+            if constexpr (F16) {
+                ox = h2f(r.x & 0xffffu); oy = h2f(r.x >> 16); oz = h2f(r.y & 0xffffu); slot = r.y >> 16;
+            } else {
+                ox = r.x; oy = r.y; oz = r.z; slot = __float_as_uint(r.w);
+            }
+            const float4 w = wq[slot];
+            const v2f oxy = v2f{ox, oy}, ozz = v2f{oz, oz};
+            if constexpr (FIN) {
+                // a skipped slot weighs +0 exactly and a sum that started at +0 is never -0: with finite offsets
+                // "image + offset*0" leaves the image bit for bit unchanged -- no branch
+                axy[0] += oxy * w.x; axy[1] += oxy * w.y; axy[2] += oxy * w.z; axy[3] += oxy * w.w;
+                az01 += ozz * v2f{w.x, w.y};
+                az23 += ozz * v2f{w.z, w.w};
+            } else {
+                const v2f t0 = axy[0] + oxy * w.x, t1 = axy[1] + oxy * w.y, t2 = axy[2] + oxy * w.z, t3 = axy[3] + oxy * w.w;
+                const v2f u01 = az01 + ozz * v2f{w.x, w.y}, u23 = az23 + ozz * v2f{w.z, w.w};
+                const bool k0 = w.x < kMorphEps, k1 = w.y < kMorphEps, k2 = w.z < kMorphEps, k3 = w.w < kMorphEps;
+                axy[0] = k0 ? axy[0] : t0; axy[1] = k1 ? axy[1] : t1; axy[2] = k2 ? axy[2] : t2; axy[3] = k3 ? axy[3] : t3;
+                az01 = v2f{k0 ? az01.x : u01.x, k1 ? az01.y : u01.y};
+                az23 = v2f{k2 ? az23.x : u23.x, k3 ? az23.y : u23.y};
+            }
+        };
+#ifdef PK_SKIP_WALK          // timing diagnostic only (wrong results): what the kernel costs without its walk
+        if (false) {
+#else
+        if (rlen) {
+#endif
+            // Entry j+4 is requested as soon as entry j has been consumed.  The steady-state loop has no branch in its body (a
+            // refill past the row's end re-reads the last entry, which is never applied twice): the compiler counts the loads in
+            // flight and waits for exactly the oldest one.  The window's first four entries were requested by the set-up / in
+            // front of the previous pack's last stores.
+            uint32_t rb = rbase;
+            asm volatile("" : "+v"(rb));
+            uint32_t j = 0;
+            for (; j + 4 < rlen; j += 4) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    apply(e[i]);
+                    e[i] = row_entry<F16>(p.entries, rb, min(j + 4 + i, last));
+#ifndef PK_NO_SCHED_BARRIER
+                    // one entry at a time: interleaving the four entries' products would need the registers that hold the vertex's
+                    // skin data, which would then be spilled here and RELOADED between the instances' stores (see SKIN)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            }
+            apply(e[0]);
+            if (j + 1 < rlen) apply(e[1]);
+            if (j + 2 < rlen) apply(e[2]);
+            if (j + 3 < rlen) apply(e[3]);
+        }
+        // the next pack's slot weights: requested now, in LDS after this pack's instances
+        const bool more = g0 + kPkPack < gcount;
+        float4 wnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (more && wreg && uint32_t(tid) < wstride) wnext = pack_weight(g0 + kPkPack, uint32_t(tid));
+        // coordinate = base + image (poser_impl.inl:407): instance 0 in registers, 1..3 to this thread's words of mp
+        v2f cxy = ps.pxy + axy[0];
+        float cz = ps.pz + az01.x;
+        {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            float *m1 = reinterpret_cast<float *>(mp + 1 * kPkRegion), *m2 = reinterpret_cast<float *>(mp + 2 * kPkRegion),
+                  *m3 = reinterpret_cast<float *>(mp + 3 * kPkRegion);
+            const v2f c1 = ps.pxy + axy[1], c2 = ps.pxy + axy[2], c3 = ps.pxy + axy[3];
+            m1[t] = c1.x; m1[kTileVerts + t] = c1.y; m1[2 * kTileVerts + t] = ps.pz + az01.y;
+            m2[t] = c2.x; m2[kTileVerts + t] = c2.y; m2[2 * kTileVerts + t] = ps.pz + az23.x;
+            m3[t] = c3.x; m3[kTileVerts + t] = c3.y; m3[2 * kTileVerts + t] = ps.pz + az23.y;
+        }
+        PK_STAMP(1);
+        // ---- SKIN: the pack's instances, one barrier each.  No vector-memory LOAD may sit in here: it would have to wait for the
+        // previous instance's stores to drain (vmcnt is in order), microseconds under a saturated HBM. ---------------------------
+        auto instance = [&](const uint32_t j, auto last_tag) {
+            constexpr bool kLast = decltype(last_tag)::value;       // the pack's fourth instance: the next walk's row head goes out with it
+            const uint32_t inst = first_instance(g0) + j;
+            const size_t vbase = size_t(inst) * p.nv + v0;
+            const uint32_t sh4 = al ? uint32_t((vbase * 3) & 3) : 0u, sh8 = al ? uint32_t((vbase * 3) & 7) : 0u;
+            unsigned char *ia = mp + j * kPkRegion, *ib = imgB + buf * kSoaImgBytes;
+            // (in place: the values stay in their registers, the compiler merely stops treating them as loop invariants -- whose
+            // derived values it would otherwise carry around the loops in registers of their own)
+            asm volatile("" : "+v"(ps.meta), "+v"(ps.b01), "+v"(ps.b23), "+v"(ps.w0), "+v"(ps.w1), "+v"(ps.w2), "+v"(ps.w3), "+v"(ps.nxy),
+                         "+v"(ps.nz));
+            const uint32_t meta = ps.meta, b01 = ps.b01, b23 = ps.b23;
+            const float w0 = ps.w0, w1 = ps.w1, w2 = ps.w2, w3 = ps.w3, nx = ps.nxy.x, ny = ps.nxy.y, nz = ps.nz;
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            if (meta >> 12) {
+                const M12 m = skin_matrix_packed((meta >> 10) & 3u, b01, b23, w0, w1, w2, w3, pal + size_t(g0 + j) * p.pal_stride);
+                v2f oxy, rxy;
+                float oz, rz;
+                xform_pos(m, cxy, cz, oxy, oz);
+                xform_nrm(m, v2f{nx, ny}, nz, rxy, rz);
+                oxy = oxy * p.pos_scale;                 // a separate multiply after the transform (main.cpp:848-850)
+                oz = oz * p.pos_scale;
+                const uint32_t perm3 = (meta & 1023u) * 3;
+                float *B = reinterpret_cast<float *>(ib) + sh4 + perm3;
+                if constexpr (LAYOUT == MMDX_OUT_SOA) {
+                    float *A = reinterpret_cast<float *>(ia) + sh4 + perm3;
+                    A[0] = oxy.x; A[1] = oxy.y; A[2] = oz;
+                } else {
+                    unsigned short *A = reinterpret_cast<unsigned short *>(ia) + sh8 + perm3;
+                    A[0] = f2h(oxy.x); A[1] = f2h(oxy.y); A[2] = f2h(oz);
+                }
+                B[0] = rxy.x; B[1] = rxy.y; B[2] = rz;
+            }
+            if (!kLast) {                   // the next instance's coordinate, before anybody may overwrite it with that instance's image
+                const float *mn = reinterpret_cast<const float *>(mp + (j + 1) * kPkRegion);
+                cxy = v2f{mn[t], mn[kTileVerts + t]};
+                cz = mn[2 * kTileVerts + t];
+            }
+            PK_STAMP(2);
+            __syncthreads();
+            PK_STAMP(3);
+            // the head of the row for the next pack's walk goes out IN FRONT of the pack's last stores: its round trip then runs
+            // beside their drain instead of behind it
+            if constexpr (kLast) { if (more) row_head(); }
+            if constexpr (LAYOUT == MMDX_OUT_SOA) {
+                float *oa = reinterpret_cast<float *>(p.out_a), *ob = reinterpret_cast<float *>(p.out_b);
+                if (fast)
+                    copy_out_fast<kPkThreads, kTileVerts * 12 / 16, kTileVerts * 12 / 16>(
+                        ia, uint32_t(ib - ia), reinterpret_cast<float4 *>(oa + vbase * 3), reinterpret_cast<float4 *>(ob + vbase * 3), t);
+                else
+                    copy_out2<kPkThreads, float, float>(ia, oa, vbase * 3, sh4, nvt * 3, ib, ob, vbase * 3, sh4, nvt * 3, al, t);
+            } else {
+                unsigned short *oa = reinterpret_cast<unsigned short *>(p.out_a);
+                float *ob = reinterpret_cast<float *>(p.out_b);
+                if (fast)
+                    copy_out_fast<kPkThreads, kTileVerts * 6 / 16, kTileVerts * 12 / 16>(
+                        ia, uint32_t(ib - ia), reinterpret_cast<float4 *>(oa + vbase * 3), reinterpret_cast<float4 *>(ob + vbase * 3), t);
+                else
+                    copy_out2<kPkThreads, unsigned short, float>(ia, oa, vbase * 3, sh8, nvt * 3, ib, ob, vbase * 3, sh4, nvt * 3, al, t);
+            }
+            buf ^= 1u;
+            PK_STAMP(4);
+        };
+#ifdef PK_SKIP_SKIN
+        if (cz == 12345.678f && cxy.x == 9.75f) instance(0, std::true_type{});      // (keeps the walk's results alive)
+#else
+#pragma unroll 1
+        for (uint32_t j = 0; j + 1 < kPkPack; ++j) {
+            if (first_instance(g0) + j >= p.ni) break;
+            instance(j, std::false_type{});
+        }
+        if (first_instance(g0) + kPkPack - 1 < p.ni) instance(kPkPack - 1, std::true_type{});
+#endif
+#ifdef PK_SKIP_SKIN          // timing diagnostic only (wrong results): the walk alone -- instances are skipped by the macro below
+#endif
+        if (more) {
+            // every wave has left this pack's walk (it passed the instances' barriers): the weights can be replaced.  The barrier
+            // also closes the last instance's copy-out reads before the next walk's coordinates land in mp.
+            if (wreg) {
+                if (uint32_t(tid) < wstride) wq[tid] = wnext;
+            } else {
+                for (uint32_t i = tid; i < wstride; i += kPkThreads) wq[i] = pack_weight(g0 + kPkPack, i);
+            }
+            __syncthreads();
+        }
+        PK_STAMP(5);
+    }
+#ifdef PK_STAMPS
+    if ((tid & 63) == 0 && p.stamps) {
+        unsigned long long *o = p.stamps + (size_t(blockIdx.x) * 8 + (uint32_t(tid) >> 6)) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = st_acc[k];
+        o[6] = st_begin; o[7] = st_t;
+    }
+#endif
 }
 
 // ---- ONE frame of ONE model (ni == 1): the reference's per-frame call (main.cpp:1821) -------------------------------------
@@ -1190,7 +1538,84 @@ size_t deform_lds_bytes(int threads, int layout, int morph, uint32_t group, uint
 
 #endif  // !MMDX_FAST_MATH
 
+#ifndef MMDX_FAST_MATH
+// pack_kernel: [palettes of the group][slot weights of one pack][kPkPack coordinate / position-image regions][2 normal images]
+size_t pack_lds_bytes(uint32_t group, uint32_t max_tile_bones, uint32_t ns, uint32_t *stage_off, uint32_t *w_off, uint32_t *mp_off) {
+    size_t off = size_t(group) * max_tile_bones * 48;
+    *w_off = uint32_t(off);
+    off += size_t(ns + 1) * 16;
+    *mp_off = uint32_t(off);
+    off += size_t(kPkPack) * kPkRegion;
+    *stage_off = uint32_t(off);
+    off += 2 * size_t(kSoaImgBytes);
+    return off;
+}
+#endif  // !MMDX_FAST_MATH
+
+namespace {
+KernelFn pick_pack(int layout, bool f16, bool finite) {
+    if (f16) {
+        if (layout != MMDX_OUT_SOA_POS16) return nullptr;
+        return finite ? pack_kernel<MMDX_OUT_SOA_POS16, true, true> : pack_kernel<MMDX_OUT_SOA_POS16, true, false>;
+    }
+    if (layout != MMDX_OUT_SOA) return nullptr;
+    return finite ? pack_kernel<MMDX_OUT_SOA, false, true> : pack_kernel<MMDX_OUT_SOA, false, false>;
+}
+}  // namespace
+
+hipError_t MMDX_K(launch_pack)(int layout, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes, hipStream_t stream) {
+    KernelFn fn = pick_pack(layout, f16, p.finite_offsets != 0);
+    if (!fn || kTileVerts != 512) return hipErrorInvalidValue;
+    DeformParams q = p;
+    q.ntiles = ntiles;
+    q.ngroups = (p.ni + p.group - 1) / p.group;
+    q.rem_per_xcd = ((ntiles & 7u) * q.ngroups + 7u) / 8u;
+    const dim3 grid(8u * ((ntiles >> 3) * q.ngroups + q.rem_per_xcd));
+#ifdef PK_STAMPS
+    static unsigned long long *stamps = nullptr;
+    static size_t stamps_n = 0;
+    const size_t need = size_t(grid.x) * 64;
+    if (stamps_n < need) { if (stamps) (void)hipFree(stamps); (void)hipMalloc(&stamps, need * 8); stamps_n = need; }
+    (void)hipMemsetAsync(stamps, 0, need * 8, stream);
+    q.stamps = stamps;
+#endif
+    hipLaunchKernelGGL(fn, grid, dim3(kPkThreads), lds_bytes, stream, q);
+#ifdef PK_STAMPS
+    {
+        static int calls = 0;
+        if (++calls % 16 == 0) {            // now and then: wait, fetch, print the means (diagnostic build only)
+            (void)hipStreamSynchronize(stream);
+            std::vector<unsigned long long> h(need);
+            (void)hipMemcpy(h.data(), stamps, need * 8, hipMemcpyDeviceToHost);
+            const char *names[6] = {"sync/top", "walk", "skin", "barrier", "copy-out", "pack-end"};
+            for (int w : {0, 3, 7}) {
+                double acc[6] = {0, 0, 0, 0, 0, 0}, life = 0; size_t n = 0;
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (size_t b = 0; b < grid.x; ++b) {
+                    const unsigned long long *r = h.data() + (b * 8 + w) * 8;
+                    if (!r[7]) continue;
+                    for (int k = 0; k < 6; ++k) acc[k] += double(r[k]);
+                    life += double(r[7] - r[6]); ++n;
+                    t0 = std::min(t0, r[6]); t1 = std::max(t1, r[7]);
+                }
+                if (!n) continue;
+                std::fprintf(stderr, "pk-stamps wave %d: n=%zu life %.0f ticks |", w, n, life / n);
+                for (int k = 0; k < 6; ++k) std::fprintf(stderr, " %s %.0f (%.0f%%)", names[k], acc[k] / n, 100.0 * acc[k] / life);
+                std::fprintf(stderr, " | kernel span %llu ticks\n", t1 - t0);
+            }
+        }
+    }
+#endif
+    return hipGetLastError();
+}
+
 hipError_t MMDX_K(prepare_kernels)() {
+    for (int f16 = 0; f16 < 2; ++f16)
+        for (int fin = 0; fin < 2; ++fin) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pick_pack(f16 ? MMDX_OUT_SOA_POS16 : MMDX_OUT_SOA, f16 != 0, fin != 0)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
     for (int threads = 256; threads <= 512; threads += 256)
       for (int f16 = 0; f16 < 2; ++f16)
         for (int layout = 0; layout < 3; ++layout)

@@ -56,6 +56,7 @@ struct DeformParams {
     uint32_t pal_stride;         // float4 per instance in LDS (= max_tile_bones * 3)
     uint32_t stage_off;          // byte offsets inside dynamic LDS
     uint32_t w_off;
+    uint32_t mp_off;             // pack_kernel: the coordinate / position-image regions
     float pos_scale;
     uint32_t out_aligned;        // out_a and out_b are 16-byte aligned
     uint32_t finite_offsets;     // every vertex-morph offset is finite (branch-free morph skip is exact)
@@ -63,6 +64,10 @@ struct DeformParams {
     uint32_t tile_order;         // MMDX_CREATE_TILE_ORDER: outputs in the engine's vertex order (tile-local class sort), stored straight
                                  // from registers -- no LDS image, no per-instance barrier
     uint32_t write_through;      // launch the write-through flavour of the copy-out (api.cpp sets it only where deform_has_write_through())
+    uint32_t stagger;            // per-instance-morph kernels: first-round workgroups of residency slot k start k * stagger * 64 cycles late,
+                                 // so that the workgroups sharing a CU are not all in their walk (or all in their stores) at once
+    uint32_t slots_per_cu;       // ... with this many workgroups resident per CU
+    unsigned long long *stamps;  // diagnostic builds of pack_kernel only (PK_STAMPS): per-wave cycle counters; nullptr in the product
     uint32_t *morph_seen;        // kMorphFused1 crowds: the handle's RatesSeen record; a launch that overwrites `morphed` clears its
                                  // valid word (the record no longer describes what `morphed` holds)
 };
@@ -94,6 +99,11 @@ constexpr bool deform_has_write_through(int threads, int layout, int morph, bool
 
 hipError_t launch_deform(int threads, int layout, int morph, bool f16, const DeformParams &p,
                          uint32_t ntiles, size_t lds_bytes, hipStream_t stream);
+// Per-instance morph weights, packs of 4 instances, 512 threads (kernels.hip pack_kernel): SoA f32 and f16-position layouts, original
+// vertex order.  p.group a multiple of 4; LDS offsets from pack_lds_bytes.
+size_t pack_lds_bytes(uint32_t group, uint32_t max_tile_bones, uint32_t ns, uint32_t *stage_off, uint32_t *w_off, uint32_t *mp_off);
+hipError_t launch_pack(int layout, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_pack_fast(int layout, bool f16, const DeformParams &p, uint32_t ntiles, size_t lds_bytes, hipStream_t stream);
 // One frame of one model (ni == 1, kMorphNone / kMorphFused1): latency-ordered kernel, a workgroup = `threads` (128 / 256) sorted
 // slots of a tile, direct stores.  LDS: the tile's palette, then the slot weights at *w_off.
 size_t frame_lds_bytes(int morph, uint32_t max_tile_bones, uint32_t ns, uint32_t *w_off);

@@ -526,7 +526,7 @@ def test_config2_full_size_single_frames(oracle):
             gu.assert_bits_equal(v32, oracle.repack32(m, ep, en, 0.1), f"config2 frame {f} v32")
 
 
-def test_config2_full_size_64_frames_per_launch(oracle):
+def test_config2_full_size_64_frames_per_launch(oracle, fused_shape):
     """BASELINE config 2, the bandwidth form bench.py times: 64 frames of the 50k model in ONE launch with
     per-frame morph weights (kMorphFused4: 512-thread workgroups, 8 instances per walk over a morph row), all
     buffers in HBM -- EVERY frame, every vertex against the oracle."""
@@ -744,7 +744,7 @@ def test_config3_bucketed_vertices_bench_call_form(oracle):
             b.free()
 
 
-def test_config3prime_per_instance_morph_crowd_sample(oracle):
+def test_config3prime_per_instance_morph_crowd_sample(oracle, fused_shape):
     """Config 3' (every instance its own facial state, 1024 x 50k, fused gather): a strided sample of 64 instances
     plus the first and last packs of 8, every vertex against the oracle."""
     m = synth.make_config("config3_crowd")
@@ -764,7 +764,7 @@ def test_config3prime_per_instance_morph_crowd_sample(oracle):
         d_a.free(); d_b.free()
 
 
-def test_config5_fp16_64_frames_per_launch(oracle):
+def test_config5_fp16_64_frames_per_launch(oracle, fused_shape):
     """BASELINE config 5 in the form bench.py times (64 frames per launch, f16 positions, per-frame morph weights):
     every 4th frame plus the last pack, every vertex against the f32 oracle on f16-quantised inputs."""
     m = synth.make_config("config5_256k")
@@ -1125,8 +1125,19 @@ def _batch_device(dm, rates, pals, layout, pos_scale=1.0, misalign=0):
     return a, b
 
 
+@pytest.fixture(params=[0, 1], ids=["fused4-kernel", "pack-kernel"])
+def fused_shape(request, monkeypatch, hip_lib):
+    """The two kernels per-instance morph weights can run: deform_kernel<512, ., kMorphFused4> (default) and the opt-in
+    pack_kernel (MMDX_FUSED_PACK=1, round 4's 80-register / three-workgroups-per-CU shape): same results, bit for bit."""
+    monkeypatch.setenv("MMDX_FUSED_PACK", str(request.param))
+    hip_lib.mmdx_debug_reload_env()
+    yield request.param
+    monkeypatch.delenv("MMDX_FUSED_PACK")
+    hip_lib.mmdx_debug_reload_env()
+
+
 @pytest.mark.parametrize("nv,ni", [(1, 2), (63, 5), (300, 8), (513, 9), (1000, 13), (4099, 17), (2600, 33)])
-def test_per_instance_morphs_device_resident_every_layout_and_size(oracle, nv, ni):
+def test_per_instance_morphs_device_resident_every_layout_and_size(oracle, nv, ni, fused_shape):
     """Per-instance morph weights, device-resident operands (the form bench.py times): ragged vertex counts and pack counts
     (partial last quad and pack of 8), group morphs with rates around the 1e-7 skip, SoA / 32-byte vertex (16-byte aligned and
     not) / f16 positions: bit-identical to the oracle."""
@@ -1156,7 +1167,7 @@ def test_per_instance_morphs_device_resident_every_layout_and_size(oracle, nv, n
             assert np.array_equal(b.view(np.uint32), en16.view(np.uint32).ravel()), f"{what}: f16 nrm"
 
 
-def test_per_instance_morphs_device_resident_corners(oracle):
+def test_per_instance_morphs_device_resident_corners(oracle, fused_shape):
     """Device-resident per-instance morphs: tiles that use hundreds of bones, non-finite morph offsets (the predicated skip),
     1 300 slots."""
     rng = np.random.RandomState(78)

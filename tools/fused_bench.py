@@ -19,7 +19,7 @@ from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E4
 HBM = 8000.0
 
 
-def run(name, model, ni, frames, layout, iters, f16=False):
+def run(name, model, ni, frames, layout, iters, f16=False, shared=False):
     dm = DeformModel(model, f16_positions=f16, tile_order=os.environ.get("FB_TILE_ORDER") == "1",
                      fast_math=os.environ.get("FB_FAST_MATH") == "1")                     # opt-in modes
     pals = synth.make_palettes(model, frames)
@@ -27,7 +27,7 @@ def run(name, model, ni, frames, layout, iters, f16=False):
     d_pal, d_w = DeviceBuffer.from_numpy(pals), DeviceBuffer.from_numpy(rates)
     sa, sb = dm.out_sizes(layout, ni)
     d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
-    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE
+    flags = api.PALETTE_ON_DEVICE | api.WEIGHTS_ON_DEVICE | api.OUT_ON_DEVICE | (api.WEIGHTS_SHARED if shared else 0)
     call = lambda: dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, layout, flags)   # noqa: E731
     # FB_SWEEP="MMDX_XCD_CHUNK=0,1,2,4": one launch-shape override swept in this process (interleaved, FB_ROUNDS rounds, medians)
     if os.environ.get("FB_SWEEP"):
@@ -71,6 +71,8 @@ def main():
             run("c2x1", m, 1, np.arange(1) + 17, api.OUT_SOA, iters * 10)
         if "c3p" in which:
             run("c3prime", m, 1024, (np.arange(1024) * 7) % 600, api.OUT_SOA, max(iters // 2, 5))
+        if "c3" in which:          # the shared-morph crowd kernel on the same box, for reference (morph pass skipped after the first call)
+            run("c3crowd", m, 1024, (np.arange(1024) * 7) % 600, api.OUT_SOA, max(iters // 2, 5), shared=True)
     if "c5" in which:
         m5 = synth.make_config("config5_256k")
         run("c5x64", m5, 64, np.arange(64), api.OUT_SOA_POS16, iters, f16=True)
