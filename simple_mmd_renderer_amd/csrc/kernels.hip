@@ -347,6 +347,43 @@ __device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint
     row_consume<F16, B>(entries, base, len, h, body);
 }
 
+// The same walk through a ROLLING window (round 4): entry j+D is requested as soon as entry j has been consumed -- D loads in
+// flight in ONE register set (row_consume keeps a current and a next batch, 2 x 4 entries, and copies one into the other), and the
+// steady-state loop has no branch in its body (a refill past the row's end re-reads the last entry, which is never applied
+// twice), so the compiler counts the loads in flight and waits for exactly the oldest one instead of draining the queue at
+// every batch.  `len` must be wave-uniform (a scalar: the slice's padded length).
+#ifndef MMDX_WALK_DEPTH32
+#define MMDX_WALK_DEPTH32 4        // entries in flight per lane, f32 table (16-byte entries: 4 registers each)
+#endif
+#ifndef MMDX_WALK_DEPTH16
+#define MMDX_WALK_DEPTH16 4        // ... f16 table (8-byte entries: 2 registers each)
+#endif
+template <bool F16, typename Body>
+__device__ __forceinline__ void walk_rolling(const void *entries, uint32_t base, uint32_t len, Body body) {
+    using Raw = typename RawEntry<F16>::type;
+    constexpr uint32_t D = F16 ? MMDX_WALK_DEPTH16 : MMDX_WALK_DEPTH32;
+    if (len == 0) return;
+    auto apply = [&](const Raw r) {
+        if constexpr (F16) body(h2f(r.x & 0xffffu), h2f(r.x >> 16), h2f(r.y & 0xffffu), uint32_t(r.y >> 16));
+        else body(r.x, r.y, r.z, __float_as_uint(r.w));
+    };
+    const uint32_t last = len - 1;
+    Raw e[D];
+#pragma unroll
+    for (uint32_t i = 0; i < D; ++i) e[i] = row_entry<F16>(entries, base, min(i, last));
+    uint32_t j = 0;
+    for (; j + D < len; j += D) {
+#pragma unroll
+        for (uint32_t i = 0; i < D; ++i) {
+            apply(e[i]);
+            e[i] = row_entry<F16>(entries, base, min(j + D + i, last));
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < D; ++i)
+        if (i == 0 || j + i < len) apply(e[i]);
+}
+
 // Group-morph recursion of one slot (UpdateMorphTransform, poser_impl.inl:328-339): rate[top] times the
 // nested groups' sub-rates, with the `< 1e-7` skip after every factor; a skipped slot weighs 0.
 __device__ __forceinline__ float slot_weight(const float *rates, const uint32_t *slot_top,
@@ -717,6 +754,17 @@ __device__ __forceinline__ void stagger_start(const DeformParams &p) {
     for (uint32_t k = 0; k < round * p.stagger; k += 100) __builtin_amdgcn_s_sleep(100);
 }
 
+// The walk of the per-instance-morph mode: MMDX_WALK_ROLLING=1 (build-time A/B knob) takes the rolling window; a sorted slot's row
+// length is the same for the 64 lanes of its wave (one slice), lanes past the tile's end included or all of them 0.
+#ifndef MMDX_WALK_ROLLING
+#define MMDX_WALK_ROLLING 1
+#endif
+template <bool F16, bool ROLLING, typename Body>
+__device__ __forceinline__ void fused4_walk(const void *entries, uint32_t rb, uint32_t rlen, Body body) {
+    if constexpr (ROLLING && MMDX_WALK_ROLLING != 0) walk_rolling<F16>(entries, rb, __builtin_amdgcn_readfirstlane(rlen), body);
+    else for_row<F16>(entries, rb, rlen, body);
+}
+
 // ---- the deformation kernel ----------------------------------------------------------------------
 // THREADS = 512: one sorted slot per lane, 8 waves per workgroup; THREADS = 256: two slots per lane.
 template <int THREADS, int LAYOUT, int MORPH, bool F16, bool TILE, bool WT = false>
@@ -859,7 +907,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
                     // the image bit-for-bit unchanged: the skip needs no branch.
-                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
+                    fused4_walk<F16, !TILE>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
                         const v2f oxy = v2f{ox, oy};
@@ -880,7 +928,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     });
                 } else {
 #ifndef FUSED4_SKIP_WALK
-                    for_row<F16>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
+                    fused4_walk<F16, !TILE>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
                         const v2f oxy = v2f{ox, oy};
