@@ -358,30 +358,45 @@ __device__ __forceinline__ void for_row(const void *entries, uint32_t base, uint
 #ifndef MMDX_WALK_DEPTH16
 #define MMDX_WALK_DEPTH16 4        // ... f16 table (8-byte entries: 2 registers each)
 #endif
-template <bool F16, typename Body>
-__device__ __forceinline__ void walk_rolling(const void *entries, uint32_t base, uint32_t len, Body body) {
+template <bool F16>
+struct WalkHead {                   // the first D entries of a row, requested ahead of the walk that consumes them
+    static constexpr uint32_t D = F16 ? MMDX_WALK_DEPTH16 : MMDX_WALK_DEPTH32;
+    typename RawEntry<F16>::type e[D];
+};
+template <bool F16>
+__device__ __forceinline__ void walk_head(const void *entries, uint32_t base, uint32_t len, WalkHead<F16> &h) {
     using Raw = typename RawEntry<F16>::type;
-    constexpr uint32_t D = F16 ? MMDX_WALK_DEPTH16 : MMDX_WALK_DEPTH32;
+    const uint32_t last = len ? len - 1 : 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < WalkHead<F16>::D; ++i) h.e[i] = len ? row_entry<F16>(entries, base, min(i, last)) : Raw{};
+}
+template <bool F16, typename Body>
+__device__ __forceinline__ void walk_from_head(const void *entries, uint32_t base, uint32_t len, WalkHead<F16> &h, Body body) {
+    using Raw = typename RawEntry<F16>::type;
+    constexpr uint32_t D = WalkHead<F16>::D;
     if (len == 0) return;
     auto apply = [&](const Raw r) {
         if constexpr (F16) body(h2f(r.x & 0xffffu), h2f(r.x >> 16), h2f(r.y & 0xffffu), uint32_t(r.y >> 16));
         else body(r.x, r.y, r.z, __float_as_uint(r.w));
     };
     const uint32_t last = len - 1;
-    Raw e[D];
-#pragma unroll
-    for (uint32_t i = 0; i < D; ++i) e[i] = row_entry<F16>(entries, base, min(i, last));
     uint32_t j = 0;
     for (; j + D < len; j += D) {
 #pragma unroll
         for (uint32_t i = 0; i < D; ++i) {
-            apply(e[i]);
-            e[i] = row_entry<F16>(entries, base, min(j + D + i, last));
+            apply(h.e[i]);
+            h.e[i] = row_entry<F16>(entries, base, min(j + D + i, last));
         }
     }
 #pragma unroll
     for (uint32_t i = 0; i < D; ++i)
-        if (i == 0 || j + i < len) apply(e[i]);
+        if (i == 0 || j + i < len) apply(h.e[i]);
+}
+template <bool F16, typename Body>
+__device__ __forceinline__ void walk_rolling(const void *entries, uint32_t base, uint32_t len, Body body) {
+    WalkHead<F16> h;
+    walk_head<F16>(entries, base, len, h);
+    walk_from_head<F16>(entries, base, len, h, body);
 }
 
 // Group-morph recursion of one slot (UpdateMorphTransform, poser_impl.inl:328-339): rate[top] times the
@@ -647,10 +662,13 @@ __device__ __forceinline__ M12 skin_matrix(const Slot &q, const float4 *P) {
 // One instance: skin the thread's slots with the palette at P (LDS), scatter the results to the LDS image `img`
 // (undoing the class sort), ONE workgroup barrier, then write the image out with coalesced 16-byte stores.
 // `inst` = the instance's index in the output arrays, cxy / cz = the (morphed) positions of the thread's slots.
-template <int THREADS, int LAYOUT, int VPT, bool TILE, bool ALL_FAST, bool WT = false>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_barrier`: called between the barrier and the copy-out -- whatever it requests from memory is in the queue IN FRONT of this
+// instance's stores (vmcnt is in order: a load issued behind them would wait for their drain).
+template <int THREADS, int LAYOUT, int VPT, bool TILE, bool ALL_FAST, bool WT = false, typename Hook = NoHook>
 __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot (&sl)[VPT], const float4 *P,
                                               unsigned char *img, uint32_t inst, uint32_t v0, uint32_t nvt,
-                                              const v2f (&cxy)[VPT], const float (&cz)[VPT], int tid) {
+                                              const v2f (&cxy)[VPT], const float (&cz)[VPT], int tid, Hook after_barrier = Hook()) {
     const size_t vbase = size_t(inst) * p.nv + v0;  // first output vertex of this tile
     const bool al = p.out_aligned != 0;
     const uint32_t sh4 = al ? uint32_t((vbase * 3) & 3) : 0u;
@@ -709,6 +727,7 @@ __device__ __forceinline__ void skin_instance(const DeformParams &p, const Slot 
     }
     if constexpr (TILE) return;
     __syncthreads();
+    after_barrier();
     // ALL_FAST: the kernel found, once per workgroup, that every instance of this full tile starts on a 16-byte boundary; the
     // generic copy-out is then not even compiled into the instance loop (1-2 % of the crowd step: measured)
     const bool fast = ALL_FAST || (al && nvt == kTileVerts && sh4 == 0 && sh8 == 0);
@@ -759,6 +778,9 @@ __device__ __forceinline__ void stagger_start(const DeformParams &p) {
 #ifndef MMDX_WALK_ROLLING
 #define MMDX_WALK_ROLLING 1
 #endif
+#ifndef MMDX_WALK_PREFETCH
+#define MMDX_WALK_PREFETCH 0       // the next pack's row head requested in front of a pack's last stores: 147 VGPRs instead of 118 (f32), i.e.
+#endif                             // one workgroup per CU instead of two, or 48 spills under a 128-register bound -- off; pack_kernel does it for free
 template <bool F16, bool ROLLING, typename Body>
 __device__ __forceinline__ void fused4_walk(const void *entries, uint32_t rb, uint32_t rlen, Body body) {
     if constexpr (ROLLING && MMDX_WALK_ROLLING != 0) walk_rolling<F16>(entries, rb, __builtin_amdgcn_readfirstlane(rlen), body);
@@ -831,9 +853,9 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
     auto instances = [&](auto all_fast_tag) {
     constexpr bool kAllFast = decltype(all_fast_tag)::value;
     // the image is double buffered: the next instance writes the other one, so one barrier per instance is enough
-    auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT]) {
+    auto run_instance = [&](uint32_t g, const v2f (&cxy)[VPT], const float (&cz)[VPT], auto hook) {
         skin_instance<THREADS, LAYOUT, VPT, TILE, kAllFast, WT>(p, sl, pal + size_t(g) * p.pal_stride, stage + buf * kStage,
-                                                           inst0 + g * istep, v0, nvt, cxy, cz, tid);
+                                                           inst0 + g * istep, v0, nvt, cxy, cz, tid, hook);
         buf ^= 1u;
     };
 
@@ -843,7 +865,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         float cz[VPT];
 #pragma unroll
         for (int k = 0; k < VPT; ++k) { cxy[k] = sl[k].pxy; cz[k] = sl[k].pz; }
-        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cxy, cz);
+        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cxy, cz, NoHook{});
     } else if constexpr (MORPH == kMorphFused1) {
         // vertex_image = 0; for each applied entry: image = image + offset*rate
         // (poser_impl.inl:340-346); coordinate = base + image (:407)
@@ -869,7 +891,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         }
         // the group's instances: one for a single-model frame; for a crowd with a shared facial state every workgroup
         // repeats its tile's short walk (the table stays in its XCD's L2) instead of waiting for a separate morph pass
-        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cxy, cz);
+        for (uint32_t g = 0; g < gcount; ++g) run_instance(g, cxy, cz, NoHook{});
     } else {
         // Slot weights of kQuads instance quads live in LDS at a time (kQuads x (NS+1) x float4): one pass over
         // a vertex's morph row then serves 4*kQuads instances, so the table is walked (and its L2 latency paid)
@@ -884,7 +906,14 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
         // them: their load round trip is hidden and one barrier separates the packs.  (Otherwise: staged between the
         // packs.)
         const bool wreg = wcount <= uint32_t(THREADS);
-        for (uint32_t g0 = 0; g0 < gcount; g0 += kPack) {
+        // One slot per lane: the head of the row (the same row for every pack) is requested ahead of the walk -- by the set-up for
+        // the first pack, then IN FRONT of each pack's last stores for the next one, so that its round trip runs beside their
+        // drain instead of behind it (MMDX_WALK_PREFETCH, build-time A/B knob).
+        constexpr bool kHead = VPT == 1 && !TILE && MMDX_WALK_ROLLING != 0 && MMDX_WALK_PREFETCH != 0;
+        WalkHead<F16> head;
+        const uint32_t hlen = __builtin_amdgcn_readfirstlane(sl[0].rlen);
+        if constexpr (kHead) walk_head<F16>(p.entries, sl[0].rb, hlen, head);
+        for (uint32_t g0 = 0; g0 < gcount;) {       // (the pack loop continues only out of the branch that prefetched `head`)
             v2f dxy[VPT][kPack];
             float dz[VPT][kPack];
 #pragma unroll
@@ -899,6 +928,10 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                         w[4] = b4.x; w[5] = b4.y; w[6] = b4.z; w[7] = b4.w;
                     }
                 };
+                auto walk = [&](auto body) {
+                    if constexpr (kHead) walk_from_head<F16>(p.entries, sl[k].rb, hlen, head, body);
+                    else fused4_walk<F16, !TILE>(p.entries, sl[k].rb, sl[k].rlen, body);
+                };
 #ifdef FUSED4_SKIP_WALK       // timing diagnostic only (wrong results): this kernel without its walk
                 if (false) {
 #else
@@ -907,7 +940,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     // A skipped slot carries w = +0 exactly (flatten_kernel) and a running sum that
                     // started at +0 can never be -0, so with FINITE offsets "image + offset*0" leaves
                     // the image bit-for-bit unchanged: the skip needs no branch.
-                    fused4_walk<F16, !TILE>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
+                    walk([&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
                         const v2f oxy = v2f{ox, oy};
@@ -928,7 +961,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                     });
                 } else {
 #ifndef FUSED4_SKIP_WALK
-                    fused4_walk<F16, !TILE>(p.entries, sl[k].rb, sl[k].rlen, [&](float ox, float oy, float oz, uint32_t slot) {
+                    walk([&](float ox, float oy, float oz, uint32_t slot) {
                         float w[kPack];
                         weights(slot, w);
                         const v2f oxy = v2f{ox, oy};
@@ -942,19 +975,25 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
             const bool more = g0 + kPack < gcount;
             float4 wnext = make_float4(0.f, 0.f, 0.f, 0.f);
             if (more && wreg && uint32_t(tid) < wcount) wnext = pack_weight(g0 + kPack, uint32_t(tid));
+            auto one = [&](int j, auto hook) {
+                v2f cxy[VPT];
+                float cz[VPT];
 #pragma unroll
-            for (int j = 0; j < kPack; ++j) {
-                if (g0 + j < gcount) {
-                    v2f cxy[VPT];
-                    float cz[VPT];
-#pragma unroll
-                    for (int k = 0; k < VPT; ++k) {
-                        cxy[k] = sl[k].pxy + dxy[k][j]; cz[k] = sl[k].pz + dz[k][j];
-                    }
-                    run_instance(g0 + j, cxy, cz);
+                for (int k = 0; k < VPT; ++k) {
+                    cxy[k] = sl[k].pxy + dxy[k][j]; cz[k] = sl[k].pz + dz[k][j];
                 }
+                run_instance(g0 + j, cxy, cz, hook);
+            };
+#pragma unroll
+            for (int j = 0; j + 1 < kPack; ++j)
+                if (g0 + j < gcount) one(j, NoHook{});
+            if (!more) {
+                if (g0 + kPack - 1 < gcount) one(kPack - 1, NoHook{});
+                break;
             }
-            if (more) {
+            if constexpr (kHead) one(kPack - 1, [&]() { walk_head<F16>(p.entries, sl[0].rb, hlen, head); });
+            else one(kPack - 1, NoHook{});
+            {
                 // every wave has left this pack's walk (it passed the barriers of the pack's instances): the weights can
                 // be replaced; one barrier before the next walk reads them.  Tile-order outputs have no per-instance barrier
                 // (skin_instance returns before it), so there a wave with short morph rows could get here while another is
@@ -967,6 +1006,7 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                 }
                 __syncthreads();
             }
+            g0 += kPack;
         }
     }
     };   // instances

@@ -199,6 +199,16 @@ void schedule_rounds(SkeletonPlan &pl) {
         }
         if (!pass) pl.n_rounds_pre = uint32_t(pl.rounds.size());
     }
+    pl.round_coop.assign(pl.rounds.size(), 0);
+    for (size_t r = 0; r < pl.rounds.size(); ++r) {
+        const RoundRec &rr = pl.rounds[r];
+        bool all_fast = rr.count > 0;
+        for (uint32_t e = 0; e < rr.count && all_fast; ++e) {
+            const BoneRec &rec = pl.bones[pl.events[rr.first + e]];
+            all_fast = (rec.bits & kBoneHasIk) && pl.iks[rec.ik].fast && pl.iks[rec.ik].nlinks <= kMaxFastLinks;
+        }
+        pl.round_coop[r] = all_fast ? 1 : 0;
+    }
 }
 
 }  // namespace

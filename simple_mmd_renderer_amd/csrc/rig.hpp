@@ -111,6 +111,8 @@ struct SkeletonPlan {
     std::vector<LinkRec> links;
     std::vector<uint32_t> events;               // bone ids, round after round
     std::vector<RoundRec> rounds;               // pre-physics rounds, then post-physics rounds
+    std::vector<uint8_t> round_coop;            // per round: every event is an IK bone whose chain is a window chain (IkRec::fast):
+                                                // the round can run on the 16-lanes-per-solve kernel (rig_kernels.hip ik_coop_kernel)
     uint32_t n_rounds_pre = 0, windows = 0;     // windows: LDS chain windows per instance
     bool nested_ik = false;                     // some IK chain holds an IK bone among its links / as its target
 };
@@ -160,6 +162,9 @@ struct SerialParams {
     uint32_t windows;                           // LDS windows per instance
     uint32_t passes;                            // bit 0: reset + pre-physics list, bit 1: post-physics list
     uint32_t nested;                            // some IK chain holds an IK bone: the kernel variant with nested solves
+    // one launch may run a SEGMENT of the schedule (the rounds in between go to ik_coop_kernel): rounds [seg_r0, seg_r1) of the
+    // lists in `passes`; seg_flags bit 0: PrePhysicsPosing's reset first, bit 1 / 2: the palette rows of the pre- / post-physics list
+    uint32_t seg_r0, seg_r1, seg_flags;
 };
 
 // The physics reactor's writes between the two lists (mmdx_skeleton_solve_post): Synchronize, then Fix.

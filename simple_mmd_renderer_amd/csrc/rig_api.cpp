@@ -463,7 +463,7 @@ static mmdx_status skeleton_solve(mmdx_skeleton_t s, mmdx_model_t model, uint32_
             HIP_TRY(launch_physics_override(pp, st));
         }
         (void)borrowed_over;
-        HIP_TRY(launch_skeleton_ordered(sp, st));
+        HIP_TRY(launch_skeleton_ordered(sp, pl.round_coop.empty() ? nullptr : pl.round_coop.data(), st));
         if (passes == 1u) { s->pre_instances = n_instances; s->pre_poses = p.poses; s->pre_morph = morph_state; }
         else s->pre_instances = 0;
     } else {

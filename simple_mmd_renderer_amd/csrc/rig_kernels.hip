@@ -755,7 +755,7 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots, DENSE ? 2 : 1) void 
     auto *lds_consts = (__attribute__((address_space(3))) float *)chain_lds +
                        size_t(p.windows) * kSolveInstances * wf + ev * (kMaxFastLinks * kLinkConstFloats);
     const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(live ? inst : 0) * p.nb * 2;
-    if (live && (p.passes & 1u)) {
+    if (live && (p.passes & 1u) && (p.seg_flags & 1u)) {
         for (uint32_t b = slot; b < p.nb; b += kSolveSlots) {   // PrePhysicsPosing's reset, poser_impl.inl:366-377
             st.set_quat(b, kStTotalRot, q_identity());
             st.set_quat(b, kStIkRot, q_identity());
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots, DENSE ? 2 : 1) void 
     float4 *out = reinterpret_cast<float4 *>(p.out) + size_t(live ? inst : 0) * p.nb * 4;
     for (uint32_t pass = 0; pass < 2; ++pass) {
         if (!(p.passes >> pass & 1u)) continue;              // the physics seam runs the two lists as two launches
-        const uint32_t r0 = pass ? p.n_rounds_pre : 0, r1 = pass ? p.n_rounds : p.n_rounds_pre;
+        const uint32_t r0 = max(pass ? p.n_rounds_pre : 0u, p.seg_r0), r1 = min(pass ? p.n_rounds : p.n_rounds_pre, p.seg_r1);
         for (uint32_t r = r0; r < r1; ++r) {
             const RoundRec rr = p.rounds[r];
             if (live && ev < rr.count) {
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots, DENSE ? 2 : 1) void 
             __syncthreads();
         }
         const uint32_t s0 = pass ? p.n_pre : 0, s1 = pass ? p.nb : p.n_pre;
-        if (live) {
+        if (live && (p.seg_flags >> (1 + pass) & 1u)) {
             for (uint32_t s = s0 + slot; s < s1; s += kSolveSlots) {   // UpdateBoneSkinningMatrix of this list
                 const uint32_t b = p.order[s];
                 const BoneRec rec = p.bones[b];
@@ -797,6 +797,254 @@ __global__ __launch_bounds__(kSolveInstances * kSolveSlots, DENSE ? 2 : 1) void 
         }
         __syncthreads();                                     // the second list's IK may rewrite these bones
     }
+}
+
+// ---- CCD-IK with SIXTEEN lanes per solve (round 4) ---------------------------------------------------------------------------------
+// One solve on one lane (ccd above) is a dependent stream of ~230 k instructions: a 4x4 product is 112 of them, and after every
+// link rotation the chain below it is re-placed with one product per link plus one for the target (poser_impl.inl:292-302).  A
+// product's sixteen elements are independent 4-term sums, so here a solve owns 16 lanes, lane (r, c) holds element [r][c] of every
+// matrix that is live, and a product is 4 quad broadcasts (row of A) + 4 broadcasts across the quads (column of B) + 4 multiplies
+// + 3 adds -- the same per-element operation order (Matrix4x4::operator*, math_impl.inl:984-1003), so the same bits.  Everything
+// else of a link step (directions, axis, angle, quaternions, Euler limits: poser_impl.inl:214-290) is computed by all 16 lanes
+// alike from the same inputs: no exchange, identical values.  Window chains only (IkRec::fast): link j hangs off link j+1, the
+// target off link 0, no append bone, no nested solve; the loop below is ccd()'s kWindow path statement for statement, with one more
+// reuse of an unchanged value: the local matrix of a link BEFORE its parent product depends only on that link's own rotation and
+// translation, so it is cached (lpre) and recomputed when the link is turned -- where the reference recomputes the same value.
+// A block is 16 solves of ONE IK bone for 16 consecutive instances: the four solves of a wave run the same chain.
+constexpr uint32_t kCoopLanes = 16, kCoopSolves = 16;
+constexpr uint32_t kCoopCells = kMaxFastLinks + 2;                       // links, target, the root-most link's parent
+constexpr uint32_t kCoopLpre = kCoopCells * kSerialStateFloats;          // float offsets inside a solve's LDS window
+constexpr uint32_t kCoopConsts = kCoopLpre + kMaxFastLinks * 16;
+constexpr uint32_t kCoopTpre = kCoopConsts + kMaxFastLinks * kLinkConstFloats;
+constexpr uint32_t kCoopMisc = kCoopTpre + 16;                           // ik_pos xyz, run flag
+constexpr uint32_t kCoopWindow = (kCoopMisc + 4) | 1u;                   // odd: the four solves of a wave fall into different banks
+
+template <int K>
+__device__ __forceinline__ float quad_lane(float v) {                    // the value lane K of this lane's quad holds
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ float quad_of_group(float v) {                // ... lane (quad K, same position in the quad) of the 16-group
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x13 | ((K << 2) << 5)));
+}
+template <int L>
+__device__ __forceinline__ float lane_of_group(float v) {                // ... lane L of the 16-group
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x10 | (L << 5)));
+}
+// element [r][c] of A x B from the elements of A and B this lane holds (lane = 4 r + c inside its group)
+__device__ __forceinline__ float coop_mul(float a, float b) {
+    const float a0 = quad_lane<0>(a), a1 = quad_lane<1>(a), a2 = quad_lane<2>(a), a3 = quad_lane<3>(a);
+    const float b0 = quad_of_group<0>(b), b1 = quad_of_group<1>(b), b2 = quad_of_group<2>(b), b3 = quad_of_group<3>(b);
+    return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
+}
+// this lane's element of a matrix every lane of the group holds whole
+__device__ __forceinline__ float pick16(const Mat4 &m, uint32_t sub) {
+    const bool b0 = sub & 1u, b1 = sub & 2u, b2 = sub & 4u, b3 = sub & 8u;
+    const float r0 = b0 ? (b1 ? m.m[0][3] : m.m[0][1]) : (b1 ? m.m[0][2] : m.m[0][0]);
+    const float r1 = b0 ? (b1 ? m.m[1][3] : m.m[1][1]) : (b1 ? m.m[1][2] : m.m[1][0]);
+    const float r2 = b0 ? (b1 ? m.m[2][3] : m.m[2][1]) : (b1 ? m.m[2][2] : m.m[2][0]);
+    const float r3 = b0 ? (b1 ? m.m[3][3] : m.m[3][1]) : (b1 ? m.m[3][2] : m.m[3][0]);
+    return b3 ? (b2 ? r3 : r2) : (b2 ? r1 : r0);
+}
+
+// quat_to_euler / euler_to_quat with their independent double-precision calls spread over the lanes of a quad: the two atan2 of one
+// conversion run in the even and the odd lanes, the three sincos of the other in lanes 0, 1, 2 -- the same function on the same
+// argument as the one-lane versions, so the same values; every lane ends up with all of them (quad broadcasts).
+__device__ __forceinline__ void quat_to_euler_coop(uint32_t order, const Quat q, float *r, uint32_t sub) {
+    const float ii = q.i * q.i, jj = q.j * q.j, kk = q.k * q.k;
+    const float ei = q.e * q.i, ej = q.e * q.j, ek = q.e * q.k;
+    const float ij = q.i * q.j, ik = q.i * q.k, jk = q.j * q.k;
+    const bool zxy = order == kOrderZXY, xyz = order == kOrderXYZ;
+    const float s_arg = zxy ? 2.0f * (ei + jk) : xyz ? 2.0f * (ej + ik) : 2.0f * (ek + ij);
+    const float a_y = zxy ? 2.0f * (ej - ik) : 2.0f * (ei - jk);
+    const float a_x = zxy ? 1 - 2.0f * (ii + jj) : xyz ? 1 - 2.0f * (ii + jj) : 1 - 2.0f * (ii + kk);
+    const float b_y = (zxy || xyz) ? 2.0f * (ek - ij) : 2.0f * (ej - ik);
+    const float b_x = zxy ? 1 - 2.0f * (ii + kk) : 1 - 2.0f * (jj + kk);
+    const bool odd = sub & 1u;
+    const float t = d_atan2(odd ? b_y : a_y, odd ? b_x : a_x);
+    const float s = d_asin(s_arg), a = quad_lane<0>(t), b = quad_lane<1>(t);
+    r[0] = zxy ? s : a;
+    r[1] = zxy ? a : xyz ? s : b;
+    r[2] = zxy ? b : xyz ? b : s;
+}
+__device__ __forceinline__ Quat euler_to_quat_coop(uint32_t order, const float *r, uint32_t sub) {
+    const uint32_t q4 = sub & 3u;
+    float sn, cs;
+    d_sincos((q4 == 0 ? r[0] : q4 == 1 ? r[1] : r[2]) * 0.5f, &sn, &cs);
+    const float sx = quad_lane<0>(sn), cx = quad_lane<0>(cs), sy = quad_lane<1>(sn), cy = quad_lane<1>(cs), sz = quad_lane<2>(sn),
+                cz = quad_lane<2>(cs);
+    const float ia = sx * cy * cz, ib = cx * sy * sz, ja = cx * sy * cz, jb = sx * cy * sz, ka = cx * cy * sz, kb = sx * sy * cz;
+    Quat q;
+    q.e = cx * cy * cz - sx * sy * sz;
+    q.i = order == kOrderZXY ? ia - ib : ia + ib;
+    q.j = order == kOrderXYZ ? ja - jb : ja + jb;
+    q.k = order == kOrderYZX ? ka - kb : ka + kb;
+    return q;
+}
+
+__global__ __launch_bounds__(kCoopLanes * kCoopSolves) void ik_coop_kernel(const SerialParams p, const uint32_t round) {
+    extern __shared__ float coop_lds[];
+    const RoundRec rr = p.rounds[round];
+    const uint32_t nblk = (p.ni + kCoopSolves - 1) / kCoopSolves;
+    const uint32_t ev = blockIdx.x / nblk, iblk = blockIdx.x - ev * nblk;       // which IK bone of the round, which 16 instances
+    if (ev >= rr.count) return;
+    const uint32_t solve = threadIdx.x / kCoopLanes, sub = threadIdx.x % kCoopLanes;
+    const uint32_t inst = iblk * kCoopSolves + solve;
+    if (inst >= p.ni) return;                                  // (whole 16-lane groups leave: nothing below synchronises across groups)
+    const State st = {p.state + inst, p.ni};
+    const float4 *pose = reinterpret_cast<const float4 *>(p.poses) + size_t(inst) * p.nb * 2;
+    auto *win = (__attribute__((address_space(3))) float *)coop_lds + solve * kCoopWindow;
+    const ChainState cs = {win, 0};
+    const uint32_t b = p.events[rr.first + ev];
+    const IkRec ik = p.iks[p.bones[b].ik];
+    const LinkRec *links = p.links + ik.link0;
+    const uint32_t n = ik.nlinks, tidx = n;
+    const int32_t outside = ik.outside_parent;
+    const WindowChain ch = {win + kCoopConsts, n, outside >= 0 ? int32_t(n + 1) : -1};
+    auto group_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+
+    // the event's own bone first, as the ordered kernel does (UpdateBoneTransform up to the solve), then the chain into the window
+    if (sub == 0) {
+        transform_bone(st, p, pose, inst, b);
+        win[kCoopMisc + 0] = st.at(b, kStLocal + 12); win[kCoopMisc + 1] = st.at(b, kStLocal + 13); win[kCoopMisc + 2] = st.at(b, kStLocal + 14);
+    }
+    auto copy = [&](uint32_t slot, uint32_t bone, bool in) {
+        for (uint32_t f = sub; f < kSerialStateFloats; f += kCoopLanes) {
+            if (in) cs.at(slot, f) = st.at(bone, f); else st.at(bone, f) = cs.at(slot, f);
+        }
+    };
+    for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, true);
+    copy(n, ik.target, true);
+    if (outside >= 0) copy(n + 1, uint32_t(outside), true);
+    if (sub < n) {                                             // link constants, as solve_ik lays them out
+        const LinkRec lk = links[sub];
+        const float *off = p.bones[lk.bone].local_offset;
+        auto *c = win + kCoopConsts + sub * kLinkConstFloats;
+        c[0] = off[0]; c[1] = off[1]; c[2] = off[2];
+        c[3] = __uint_as_float(lk.limited | lk.order << 8 | lk.fix << 16);
+        c[4] = lk.lo[0]; c[5] = lk.lo[1]; c[6] = lk.lo[2];
+        c[7] = lk.hi[0]; c[8] = lk.hi[1]; c[9] = lk.hi[2];
+    }
+    group_sync();
+    const V3 ik_pos = {win[kCoopMisc + 0], win[kCoopMisc + 1], win[kCoopMisc + 2]};
+    const BoneRec trec = p.bones[ik.target];
+
+    // ccd()'s preamble on the window, one lane: the links root-first, the target, the convergence test; then what the loop keeps
+    if (sub == 0) {
+        for (uint32_t i = 0; i < n; ++i) cs.set_quat(ch.idx(i), kStIkRot, q_identity());
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t j = n - i - 1, lb = links[j].bone;
+            const BoneRec rec = p.bones[lb];
+            transform_at(cs, rec, morph_of(p, lb, inst), pose[2 * size_t(lb)], pose[2 * size_t(lb) + 1], ch.idx(j), ch.par(j),
+                         uint32_t(rec.append_parent));
+        }
+        transform_at(cs, trec, morph_of(p, ik.target, inst), pose[2 * size_t(ik.target)], pose[2 * size_t(ik.target) + 1], tidx, 0,
+                     uint32_t(trec.append_parent));
+        const V3 t0 = {cs.at(tidx, kStLocal + 12), cs.at(tidx, kStLocal + 13), cs.at(tidx, kStLocal + 14)};
+        const V3 e0 = {ik_pos.x - t0.x, ik_pos.y - t0.y, ik_pos.z - t0.z};
+        win[kCoopMisc + 3] = v_dot(e0, e0) < 1e-7f ? 0.f : 1.f;
+        auto pre_parent = [&](uint32_t idx, const float *off, uint32_t at) {       // a bone's local matrix before its parent product
+            Mat4 L = q_to_matrix(cs.quat(idx, kStTotalRot));
+            L.m[3][0] = cs.at(idx, kStTotalTr + 0) + off[0];
+            L.m[3][1] = cs.at(idx, kStTotalTr + 1) + off[1];
+            L.m[3][2] = cs.at(idx, kStTotalTr + 2) + off[2];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) win[at + k] = L.m[k / 4][k % 4];
+        };
+        for (uint32_t j = 0; j < n; ++j) {
+            const V3 off = ch.offset(j);
+            const float o[3] = {off.x, off.y, off.z};
+            pre_parent(j, o, kCoopLpre + j * 16);
+        }
+        pre_parent(tidx, trec.local_offset, kCoopTpre);
+    }
+    group_sync();
+    const bool run = win[kCoopMisc + 3] != 0.f;
+    if (run) {
+        const float tpre = win[kCoopTpre + sub];
+        V3 tgt = {cs.at(tidx, kStLocal + 12), cs.at(tidx, kStLocal + 13), cs.at(tidx, kStLocal + 14)};
+        const uint32_t ikt = ik.loop / 2;
+        for (uint32_t i = 0; i < ik.loop; ++i) {
+            bool changed = false;
+            for (uint32_t j = 0; j < n; ++j) {
+                const LinkInfo lk = ch.link(j);
+                if (lk.fix == kFixAll) continue;
+                const uint32_t ls = j;
+                const int32_t lp = ch.par(j);
+                const V3 lpos = {cs.at(ls, kStLocal + 12), cs.at(ls, kStLocal + 13), cs.at(ls, kStLocal + 14)};
+                const V3 tdir = v_normalize({lpos.x - tgt.x, lpos.y - tgt.y, lpos.z - tgt.z});
+                const V3 idir = v_normalize({lpos.x - ik_pos.x, lpos.y - ik_pos.y, lpos.z - ik_pos.z});
+                V3 axis = {tdir.y * idir.z - tdir.z * idir.y, tdir.z * idir.x - tdir.x * idir.z,
+                           tdir.x * idir.y - tdir.y * idir.x};
+                if (fabsf(axis.x) < 1e-7f) axis.x = 1e-7f;
+                if (fabsf(axis.y) < 1e-7f) axis.y = 1e-7f;
+                if (fabsf(axis.z) < 1e-7f) axis.z = 1e-7f;
+                // the parent's matrix: this lane's element for the product below, the rotation part whole for the axis
+                const float loc = lp >= 0 ? cs.at(uint32_t(lp), kStLocal + sub) : (sub % 5u == 0u ? 1.f : 0.f);
+                auto L = [&](uint32_t y, uint32_t x) { return lp >= 0 ? cs.at(uint32_t(lp), kStLocal + 4 * y + x) : (x == y ? 1.f : 0.f); };
+                if (lk.limited && lk.fix != kFixNone && i < ikt) {
+                    const uint32_t row = lk.fix - kFixX;
+                    const float d = axis.x * L(row, 0) + axis.y * L(row, 1) + axis.z * L(row, 2);
+                    const float sgn = d >= 0.0f ? 1.0f : -1.0f;
+                    axis = {row == 0 ? sgn : 0.f, row == 1 ? sgn : 0.f, row == 2 ? sgn : 0.f};
+                } else {                                       // rotate(axis, loc.Transpose()).Normalize()
+                    const V3 r = {axis.x * L(0, 0) + axis.y * L(0, 1) + axis.z * L(0, 2),
+                                  axis.x * L(1, 0) + axis.y * L(1, 1) + axis.z * L(1, 2),
+                                  axis.x * L(2, 0) + axis.y * L(2, 1) + axis.z * L(2, 2)};
+                    axis = v_normalize(r);
+                }
+                float dot = v_dot(tdir, idir);
+                dot = dot < -1.0f ? -1.0f : dot;
+                dot = 1.0f < dot ? 1.0f : dot;
+                const float ac = d_acos(dot), cap = ik.angle_limit * float(j + 1);
+                const float angle = cap < ac ? cap : ac;
+                const Quat ikr_old = cs.quat(ls, kStIkRot);
+                Quat ikr = q_mul(axis_to_quat(axis, angle), ikr_old);
+                const Quat pre = cs.quat(ls, kStPreIkRot);
+                if (lk.limited) {
+                    Quat lr = q_mul(ikr, pre);
+                    float e[3];
+                    quat_to_euler_coop(lk.order, lr, e, sub);
+                    limit_euler(e, lk.lo, lk.hi, i < ikt);
+                    lr = euler_to_quat_coop(lk.order, e, sub);
+                    ikr = q_mul(lr, q_inverse(pre));
+                }
+                changed = changed || __float_as_uint(ikr.i) != __float_as_uint(ikr_old.i) || __float_as_uint(ikr.j) != __float_as_uint(ikr_old.j) ||
+                          __float_as_uint(ikr.k) != __float_as_uint(ikr_old.k) || __float_as_uint(ikr.e) != __float_as_uint(ikr_old.e);
+                // the link just turned: ik_rotation * pre-IK rotation, as the reference; its matrix before the parent product
+                const Quat total = q_mul(ikr, pre);
+                Mat4 M = q_to_matrix(total);
+                const V3 off = ch.offset(j);
+                M.m[3][0] = cs.at(ls, kStTotalTr + 0) + off.x;
+                M.m[3][1] = cs.at(ls, kStTotalTr + 1) + off.y;
+                M.m[3][2] = cs.at(ls, kStTotalTr + 2) + off.z;
+                const float mine = pick16(M, sub);
+                group_sync();                                  // every lane has read what the stores below replace
+                if (sub == 0) { cs.set_quat(ls, kStIkRot, ikr); cs.set_quat(ls, kStTotalRot, total); }
+                win[kCoopLpre + ls * 16 + sub] = mine;
+                float prev = lp >= 0 ? coop_mul(mine, loc) : mine;
+                cs.at(ls, kStLocal + sub) = prev;
+                for (uint32_t k = 1; k <= j; ++k) {            // below it nothing changed: the cached matrix IS the recomputed one
+                    const uint32_t jj = j - k;
+                    prev = coop_mul(win[kCoopLpre + jj * 16 + sub], prev);
+                    cs.at(jj, kStLocal + sub) = prev;
+                }
+                const float T = coop_mul(tpre, prev);          // the target hangs off link 0, the last one placed
+                cs.at(tidx, kStLocal + sub) = T;
+                tgt = {lane_of_group<12>(T), lane_of_group<13>(T), lane_of_group<14>(T)};
+                group_sync();                                  // the next link step reads the matrices just stored
+            }
+            const V3 err = {ik_pos.x - tgt.x, ik_pos.y - tgt.y, ik_pos.z - tgt.z};
+            if (v_dot(err, err) < 1e-7f) break;
+            if (!changed) {
+                if (i >= ikt) break;
+                i = ikt - 1;
+            }
+        }
+    }
+    group_sync();
+    for (uint32_t j = 0; j < n; ++j) copy(j, links[j].bone, false);
+    copy(n, ik.target, false);
 }
 
 // Matrix4x4<T>::Inverse(), L/util/math_impl.inl:822-897: Gauss-Jordan on [M | I] with scaled partial pivoting (a zero
@@ -951,7 +1199,50 @@ hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream) {
+static hipError_t launch_ordered_segment(const SerialParams &p, hipStream_t stream);
+
+// The whole schedule.  Rounds that consist of window-chain IK solves only (`round_coop`, host array of p.n_rounds flags; nullptr:
+// none) go to ik_coop_kernel, sixteen lanes per solve; the rounds between them to the ordered kernel, segment by segment:
+// a handful of dependent launches (~2 us each) around solves that take milliseconds on one lane.  MMDX_IK_COOP=0: one launch, as before.
+hipError_t launch_skeleton_ordered(const SerialParams &p0, const uint8_t *round_coop, hipStream_t stream) {
+    if (p0.ni == 0 || p0.nb == 0) return hipSuccess;
+    SerialParams p = p0;
+    static const int coop_env = env_int("MMDX_IK_COOP", 1);
+    bool any = false;
+    for (uint32_t r = 0; round_coop && coop_env != 0 && !p.nested && r < p.n_rounds; ++r) any = any || round_coop[r];
+    if (!any) {
+        p.seg_r0 = 0; p.seg_r1 = p.n_rounds; p.seg_flags = 7u;
+        return launch_ordered_segment(p, stream);
+    }
+    bool first = true;
+    auto segment = [&](uint32_t a, uint32_t b, uint32_t flags) -> hipError_t {
+        if (first) flags |= 1u;
+        if (a >= b && !flags) return hipSuccess;
+        first = false;
+        p.seg_r0 = a; p.seg_r1 = b; p.seg_flags = flags;
+        return launch_ordered_segment(p, stream);
+    };
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+        if (!(p.passes >> pass & 1u)) continue;
+        const uint32_t r0 = pass ? p.n_rounds_pre : 0u, r1 = pass ? p.n_rounds : p.n_rounds_pre;
+        uint32_t a = r0;
+        for (uint32_t r = r0; r < r1; ++r) {
+            if (!round_coop[r]) continue;
+            hipError_t e = segment(a, r, 0u);
+            if (e != hipSuccess) return e;
+            const uint32_t nblk = (p.ni + kCoopSolves - 1) / kCoopSolves;
+            hipLaunchKernelGGL(ik_coop_kernel, dim3(nblk * kSolveSlots), dim3(kCoopLanes * kCoopSolves), kCoopWindow * kCoopSolves * sizeof(float),
+                               stream, p, r);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            a = r + 1;
+        }
+        const hipError_t e = segment(a, r1, 2u << pass);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t launch_ordered_segment(const SerialParams &p, hipStream_t stream) {
     if (p.ni == 0 || p.nb == 0) return hipSuccess;
     const size_t lds = (size_t(window_floats(p.fast_slots)) * p.windows * kSolveInstances +
                         size_t(p.windows) * kMaxFastLinks * kLinkConstFloats) * sizeof(float);

@@ -13,7 +13,7 @@ hipError_t launch_skeleton_fk(const SkeletonParams &p, hipStream_t stream);
 // bone tracks -> palette in one launch (parallel-FK skeletons): poses of an instance live in LDS (nb * 32 bytes <= kMotionFkMaxLds)
 constexpr size_t kMotionFkMaxLds = 64 * 1024;
 hipError_t launch_motion_fk(const BoneTrackParams &t, const SkeletonParams &p, hipStream_t stream);
-hipError_t launch_skeleton_ordered(const SerialParams &p, hipStream_t stream);
+hipError_t launch_skeleton_ordered(const SerialParams &p, const uint8_t *round_coop /* host, [n_rounds] or nullptr */, hipStream_t stream);
 hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream);
 hipError_t launch_physics_override(const PhysicsParams &p, hipStream_t stream);
 
