@@ -18,9 +18,9 @@ def main(root):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f, newline="")):
                 k = r["Kernel_Name"]
-                if "deform_kernel" not in k and "pack_kernel" not in k:
+                if not any(w in k for w in ("deform_kernel", "pack_kernel", "skeleton_ordered_kernel", "ik_coop_kernel")):
                     continue
-                k = re.sub(r"^.*?((deform|pack)_kernel<[^>]*>).*$", r"\1", k)
+                k = re.sub(r"^.*?((deform|pack|skeleton_ordered)_kernel<[^>]*>|ik_coop_kernel).*$", r"\1", k)
                 acc[(variant, k, r.get("Grid_Size", "?"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for (variant, k, grid), ctr in sorted(acc.items()):
         print(f"== {variant}  {k}  grid {grid}")
