@@ -161,7 +161,7 @@ def main():
     # Output arrays through the engine's placement-aware allocator: on MI355X the store rate of the crowd
     # pattern depends on where the driver puts the arrays (bimodal); set-up work,
     # outside the timed region, and done first: the big arrays of a young process land in the fast mode
-    # within a try or two (tools/probes/shop_probe.py).  --plain-alloc takes whatever hipMalloc hands out first.
+    # within a try or two (tools/archive/probes/shop_probe.py).  --plain-alloc takes whatever hipMalloc hands out first.
     d_a, d_b, placement = dm.alloc_outputs(layout, ni, 1 if args.plain_alloc else args.shop_alloc)
     d_pal = DeviceBuffer.from_numpy(pals)
     d_w = DeviceBuffer.from_numpy(rates)
@@ -194,7 +194,7 @@ def main():
         return dm.timer_stop() / n
 
     # Settle: the first ~100 launches after an idle period run through a clock / power transient (step time
-    # overshoots by 10-25 % around launch 10-30 and decays; tools/probes/alloc_kernel_probe.py), so a 50-step
+    # overshoots by 10-25 % around launch 10-30 and decays; tools/archive/probes/alloc_kernel_probe.py), so a 50-step
     # measurement taken cold reports the transient, not the sustained rate.  Untimed batches of 20 steps until two
     # consecutive batches agree within 1.5 % and stop improving (at most 600 steps, ~0.15 s), then the contract's
     # W warm-up steps and the K timed steps.

@@ -292,7 +292,7 @@ MMDX_API mmdx_status mmdx_device_synchronize(void);
 /* Placement-aware allocation of a crowd's output arrays ([n_instances][NV] in `out_layout`; out_b stays
  * NULL for MMDX_OUT_VERTEX32).  On MI355X the store rate of the crowd's output pattern is bimodal in WHERE
  * the driver places the arrays (same virtual addresses, different physical backing: ~0.97 or ~0.75 of the
- * linear-fill rate, stable for the life of the allocation; tools/probes/alloc_probe.py, alloc_kernel_probe.py),
+ * linear-fill rate, stable for the life of the allocation; tools/archive/probes/alloc_probe.py, alloc_kernel_probe.py),
  * and the deform kernel follows it.  This helper allocates, times the store-only replay of the pattern
  * against a linear fill, and retries up to `max_tries` times (about one placement in seven is the fast
  * one; ~5 ms per try), keeping the best placement seen, then waits until the driver's background wipe of

@@ -417,7 +417,7 @@ typedef struct {
 enum { FIX_NONE = 0, FIX_X, FIX_Y, FIX_Z, FIX_ALL };
 enum { ORDER_ZXY = 0, ORDER_XYZ, ORDER_YZX };
 
-/* Optional trace of the transcendental calls of the bone solve (tools/probes/rig_mismatch_probe.py re-evaluates them on
+/* Optional trace of the transcendental calls of the bone solve (tools/archive/probes/rig_mismatch_probe.py re-evaluates them on
  * the device to tell a libm difference from anything else): records of 4 words -- function (0 sqrt, 1 sin, 2 cos,
  * 3 asin, 4 acos, 5 atan2), argument bits, second argument bits, result bits.  Not thread-safe; off by default. */
 static uint32_t *g_trace;
@@ -641,7 +641,7 @@ static void solve_ik_chain(const solve_ctx *c, uint32_t b) {
         }
         for (int k = 0; k < 3; ++k) err[k] = ik_pos[k] - tgt_pos[k];
         if (v3_dot(err, err) < (float)MMDX_EPS_D) return;
-#ifdef MMDX_IK_CYCLE_STATS      /* diagnostic build only (tools/probes/ik_cycle_probe.py): when does the chain's state start to repeat? */
+#ifdef MMDX_IK_CYCLE_STATS      /* diagnostic build only (tools/archive/probes/ik_cycle_probe.py): when does the chain's state start to repeat? */
         if (limit >= 200) {
             static unsigned long long hist[6];
             static int first[2][5];

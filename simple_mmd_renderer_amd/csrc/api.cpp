@@ -302,7 +302,7 @@ void mmdx::device_free_or_defer(void *ptr) {
 
 // The wait at the end of a call that hands results back to the host.  A per-frame call is tens of
 // microseconds of device work; hipStreamSynchronize may put the thread to sleep and then pays a wake-up that is
-// several times that on some hosts (tools/probes/host_io_probe.py), so poll the stream first and only fall back to the
+// several times that on some hosts (tools/archive/probes/host_io_probe.py), so poll the stream first and only fall back to the
 // blocking wait when the work is long.  MMDX_SPIN_WAIT_US: polling budget in microseconds (default 2000, 0 = off).
 hipError_t mmdx::wait_stream(hipStream_t stream) {
     static const int spin_us = env_int("MMDX_SPIN_WAIT_US", 2000);
@@ -581,7 +581,7 @@ mmdx_status mmdx_deform_batched(mmdx_model_t m, const mmdx_deform_args *a) {
     // ---- morph mode + slot weights ----------------------------------------------------------------
     // Morph mode.  Shared rates: a single frame and SMALL crowds with one facial state gather the morphs inside the deform
     // kernel (every workgroup repeats its tile's walk; no separate launch: 8.8 vs 10.1 us for 2 instances of the 50k
-    // model, break-even at 8, tools/probes/shared_ab.py); larger crowds run the morph pass once, in front (257 vs 269 us for
+    // model, break-even at 8, tools/archive/probes/shared_ab.py); larger crowds run the morph pass once, in front (257 vs 269 us for
     // 1024 instances) -- or not at all when the caller declares the rates unchanged since the last such call.
     bool unchanged = shared && ni > 1 && (a->flags & MMDX_MORPH_UNCHANGED);
     if (unchanged && !m->morphed_valid)
@@ -1164,7 +1164,7 @@ mmdx_status mmdx_crowd_output_alloc(mmdx_model_t m, uint32_t n_instances, int32_
         c.gbs = float(double(bytes_a + bytes_b) / (ms * 1e-3) / 1e9);
         if (launch_overrides().placement_log)
             std::fprintf(stderr, "mmdx placement try %u: a=%p b=%p store %.0f GB/s (fill %.0f)\n", tries, c.a, c.b, c.gbs, fill_gbs);
-        // measured (tools/probes/shop_probe.py): about one placement in seven is fast either way; freeing a rejected
+        // measured (tools/archive/probes/shop_probe.py): about one placement in seven is fast either way; freeing a rejected
         // candidate at once needs a few tries less on average than keeping it parked, and no extra memory.  But a process can
         // get STUCK that way -- freed blocks come straight back, 128 tries in a row in the same slow backing (seen once in the
         // round-2 profile runs: 0.279 instead of 0.227 ms per step) -- so after 8 slow tries in a row the rejected candidates

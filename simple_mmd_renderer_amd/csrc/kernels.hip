@@ -1525,7 +1525,7 @@ __global__ __launch_bounds__(kThreads) void morph_track_eval_kernel(const MorphT
 
 // ---- streaming copy / fill: the practical HBM ceiling printed next to the roofline ---------------
 // Every workgroup owns one contiguous 4 KiB chunk, workgroups in address order: the shape that
-// reached the highest store rate on MI355X in tools/probes/bw_probe (a few-thousand-block grid-stride loop
+// reached the highest store rate on MI355X in tools/archive/probes/bw_probe (a few-thousand-block grid-stride loop
 // is 30 % slower).
 __global__ __launch_bounds__(kThreads) void copy_kernel(float4 *dst, const float4 *src, size_t n) {
     const size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x;
@@ -1539,7 +1539,7 @@ __global__ __launch_bounds__(kThreads) void fill_kernel(float4 *dst, size_t n) {
 // Store-only replay of the deform kernel's output pattern: workgroup = (512-vertex tile, group of 16
 // instances) writing one piece (6 KiB for SoA) into each output array per instance.  Its rate is BIMODAL
 // on MI355X: for some placements of the arrays it runs at the linear-fill rate, for others ~25 % below,
-// and the deform kernel follows it (tools/probes/alloc_kernel_probe.py).  Used as the ceiling bench.py prints
+// and the deform kernel follows it (tools/archive/probes/alloc_kernel_probe.py).  Used as the ceiling bench.py prints
 // and as the probe of mmdx_crowd_output_alloc().
 __global__ __launch_bounds__(kThreads) void pattern_fill_kernel(float4 *a, float4 *b, uint32_t nv,
                                                                 uint32_t ni, uint32_t ntiles, uint32_t bpva,

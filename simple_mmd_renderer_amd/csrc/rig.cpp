@@ -207,7 +207,7 @@ void schedule_rounds(SkeletonPlan &pl) {
             const BoneRec &rec = pl.bones[pl.events[rr.first + e]];
             all_fast = (rec.bits & kBoneHasIk) && pl.iks[rec.ik].fast && pl.iks[rec.ik].nlinks <= kMaxFastLinks;
         }
-        pl.round_coop[r] = all_fast ? 1 : 0;
+        pl.round_coop[r] = all_fast ? uint8_t(rr.count) : uint8_t(0);
     }
 }
 

@@ -111,8 +111,9 @@ struct SkeletonPlan {
     std::vector<LinkRec> links;
     std::vector<uint32_t> events;               // bone ids, round after round
     std::vector<RoundRec> rounds;               // pre-physics rounds, then post-physics rounds
-    std::vector<uint8_t> round_coop;            // per round: every event is an IK bone whose chain is a window chain (IkRec::fast):
-                                                // the round can run on the 16-lanes-per-solve kernel (rig_kernels.hip ik_coop_kernel)
+    std::vector<uint8_t> round_coop;            // per round: its number of events if every one is an IK bone whose chain is a window
+                                                // chain (IkRec::fast) -- the round can run on the 16-lanes-per-solve kernel
+                                                // (rig_kernels.hip ik_coop_kernel) -- else 0
     uint32_t n_rounds_pre = 0, windows = 0;     // windows: LDS chain windows per instance
     bool nested_ik = false;                     // some IK chain holds an IK bone among its links / as its target
 };

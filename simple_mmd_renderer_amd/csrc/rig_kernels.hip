@@ -259,7 +259,7 @@ using ChainState = StateT<__attribute__((address_space(3))) float *, true>;  // 
 
 // float(sqrt(double(x))) is the correctly rounded f32 square root (rounding twice is innocuous for sqrt when the
 // wide format has >= 2 x 24 + 2 bits), which is what sqrtf compiles to; sincos shares its argument reduction and
-// polynomials with sin and cos.  Both substitutions checked over all 2^32 floats: tools/probes/libm_probe.hip.
+// polynomials with sin and cos.  Both substitutions checked over all 2^32 floats: tools/archive/probes/libm_probe.hip.
 __device__ __forceinline__ float d_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ void d_sincos(float x, float *s, float *c) {
     double ds, dc;
@@ -1201,13 +1201,13 @@ hipError_t launch_bone_morph(const BoneMorphParams &p, hipStream_t stream) {
 
 static hipError_t launch_ordered_segment(const SerialParams &p, hipStream_t stream);
 
-// The whole schedule.  Rounds that consist of window-chain IK solves only (`round_coop`, host array of p.n_rounds flags; nullptr:
-// none) go to ik_coop_kernel, sixteen lanes per solve; the rounds between them to the ordered kernel, segment by segment:
+// The whole schedule.  Rounds that consist of window-chain IK solves only (`round_coop`, host array of p.n_rounds entries: the
+// round's number of solves, 0 for every other round; nullptr: none) go to ik_coop_kernel, sixteen lanes per solve; the rounds between them to the ordered kernel, segment by segment:
 // a handful of dependent launches (~2 us each) around solves that take milliseconds on one lane.  MMDX_IK_COOP=0: one launch, as before.
 hipError_t launch_skeleton_ordered(const SerialParams &p0, const uint8_t *round_coop, hipStream_t stream) {
     if (p0.ni == 0 || p0.nb == 0) return hipSuccess;
     SerialParams p = p0;
-    static const int coop_env = env_int("MMDX_IK_COOP", 1);
+    const int coop_env = env_int("MMDX_IK_COOP", 1);        // (read per call: an IK launch is milliseconds, tests flip it in one process)
     bool any = false;
     for (uint32_t r = 0; round_coop && coop_env != 0 && !p.nested && r < p.n_rounds; ++r) any = any || round_coop[r];
     if (!any) {
@@ -1231,7 +1231,7 @@ hipError_t launch_skeleton_ordered(const SerialParams &p0, const uint8_t *round_
             hipError_t e = segment(a, r, 0u);
             if (e != hipSuccess) return e;
             const uint32_t nblk = (p.ni + kCoopSolves - 1) / kCoopSolves;
-            hipLaunchKernelGGL(ik_coop_kernel, dim3(nblk * kSolveSlots), dim3(kCoopLanes * kCoopSolves), kCoopWindow * kCoopSolves * sizeof(float),
+            hipLaunchKernelGGL(ik_coop_kernel, dim3(nblk * round_coop[r]), dim3(kCoopLanes * kCoopSolves), kCoopWindow * kCoopSolves * sizeof(float),
                                stream, p, r);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             a = r + 1;

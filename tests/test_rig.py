@@ -6,7 +6,7 @@ mmdx_vmd_bind_bones / mmdx_skeleton_create.  GPU tests compare the HIP kernels w
 fixture through the C ABI: bit-exact, no tolerance, on every seed used here.  (Stated tolerance of the IK solve
 beyond these seeds: its sin/cos/asin/acos/atan2 go through the device's double libm where the reference's go
 through glibc's; soaks of 4.6 million random solves found one instance whose palette differs, by 3.8e-6 at most --
-DESIGN.md section 7 row 3, tools/soak_rig.py, tools/probes/rig_mismatch_probe.py.)
+DESIGN.md section 7 row 3, tools/soak_rig.py, tools/archive/probes/rig_mismatch_probe.py.)
 """
 import os
 
@@ -585,6 +585,28 @@ def test_gpu_round_schedule_equals_sequential(monkeypatch, ni):
         seq = vmd.Skeleton(*rig)
         assert seq.info["n_solve_rounds"] == nb and sched.info["n_solve_rounds"] < nb
         gu.assert_bits_equal_or_both_nan(sched.solve(poses), seq.solve(poses), f"rig {seed}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ni", [5, 16, 70])
+def test_gpu_ik_sixteen_lanes_per_solve_equals_one_lane(monkeypatch, oracle, ni):
+    """The two CCD-IK solvers -- ik_coop_kernel (16 lanes per solve, the schedule run in segments around the IK rounds: the
+    default) and the ordered kernel's one lane per solve (MMDX_IK_COOP=0) -- on rigs dense with IK chains (every limit kind and
+    Euler order of the reference), append bones, several transform levels and post-physics bones; instance counts that leave
+    groups, waves and blocks partly empty.  Identical bits, and the oracle's on a sample."""
+    for seed in range(10):
+        nb = 30 + 9 * seed
+        rig = synth.make_ik_rig(nb, 700 + seed, n_ik=1 + seed % 7, n_append=seed % 5, post_physics=0.25, levels=1 + seed % 3)
+        poses = random_poses(ni, nb, 1700 + seed)
+        sk = vmd.Skeleton(*rig)
+        monkeypatch.setenv("MMDX_IK_COOP", "1")
+        coop = sk.solve(poses)
+        monkeypatch.setenv("MMDX_IK_COOP", "0")
+        lane = sk.solve(poses)
+        monkeypatch.delenv("MMDX_IK_COOP")
+        gu.assert_bits_equal_or_both_nan(coop, lane, f"rig {seed}")
+        want = oracle.bone_solve_full(rig[0], rig[1], poses[ni - 1], rig[2], rig[3], rig[4], rig[5], rig[6])
+        gu.assert_bits_equal_or_both_nan(coop[ni - 1], want, f"rig {seed} vs oracle")
 
 
 @pytest.mark.gpu
