@@ -260,6 +260,14 @@ using ChainState = StateT<__attribute__((address_space(3))) float *, true>;  // 
 // float(sqrt(double(x))) is the correctly rounded f32 square root (rounding twice is innocuous for sqrt when the
 // wide format has >= 2 x 24 + 2 bits), which is what sqrtf compiles to; sincos shares its argument reduction and
 // polynomials with sin and cos.  Both substitutions checked over all 2^32 floats: tools/archive/probes/libm_probe.hip.
+#ifdef IK_FAKE_LIBM     // timing diagnostic only (wrong results): what the solver costs without its double-precision libm calls
+__device__ __forceinline__ float d_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ void d_sincos(float x, float *s, float *c) { *s = x - x * x * x * 0.16f; *c = 1.0f - x * x * 0.5f; }
+__device__ __forceinline__ float d_sin(float x) { return x - x * x * x * 0.16f; }
+__device__ __forceinline__ float d_asin(float x) { return x + x * x * x * 0.16f; }
+__device__ __forceinline__ float d_acos(float x) { return 1.5707964f - (x + x * x * x * 0.16f); }
+__device__ __forceinline__ float d_atan2(float y, float x) { return y / (fabsf(x) + fabsf(y) + 1e-9f); }
+#else
 __device__ __forceinline__ float d_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ void d_sincos(float x, float *s, float *c) {
     double ds, dc;
@@ -271,6 +279,7 @@ __device__ __forceinline__ float d_sin(float x) { return float(sin(double(x))); 
 __device__ __forceinline__ float d_asin(float x) { return float(asin(double(x))); }
 __device__ __forceinline__ float d_acos(float x) { return float(acos(double(x))); }
 __device__ __forceinline__ float d_atan2(float y, float x) { return float(atan2(double(y), double(x))); }
+#endif
 
 __device__ __forceinline__ Quat q_identity() { return {0.f, 0.f, 0.f, 1.f}; }
 __device__ __forceinline__ Quat q_mul(const Quat a, const Quat q) {   // L/util/math_impl.inl:510-517
