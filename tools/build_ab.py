@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of BUILDS of libmmdx.so in ONE process on the SAME output arrays (task 1a: the cache policy of
-the copy-out stores -- plain / nt / sc1 / sc0 sc1, csrc/kernels.hip store16 -- was never tried on a kernel whose HBM bytes
-are 98.7 % write-once stores).
+"""Interleaved A/B of BUILDS of libmmdx.so in ONE process on the SAME output arrays (written in round 3 for the cache policy of
+the copy-out stores; the general tool for any build-time knob: MMDX_BUILD_DEFS=... MMDX_BUILD_OUT=build/variants/libmmdx_x.so
+python -m simple_mmd_renderer_amd.build, then)
 
-    python tools/archive/probes/store_policy_ab.py name=path.so [name=path.so ...]
+    python tools/build_ab.py name=path.so [name=path.so ...]
 
 Every library is loaded side by side (ctypes, distinct file names => distinct HIP modules), each gets its own model handle of
 BASELINE config 3; the output arrays are allocated ONCE per placement and shared, so that a placement's store mode (DESIGN.md
@@ -19,7 +19,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from simple_mmd_renderer_amd import _capi as api, synth  # noqa: E402
 from simple_mmd_renderer_amd.engine import DeformModel, DeviceBuffer  # noqa: E402
