@@ -506,6 +506,8 @@ typedef struct mmdx_skeleton_info {
     uint32_t n_bone_morph_entries;            /* applications of a bone-morph entry (groups expanded)  */
     uint32_t n_solve_rounds;                  /* ordered solver: rounds the evaluation sequence was cut
                                                  into (independent bones share a round), else 0         */
+    uint32_t n_ik_rounds_16_lanes;            /* ... of which rounds made of CCD-IK solves on plain chains: these
+                                                 run with sixteen lanes per solve (ABI 3)                */
 } mmdx_skeleton_info;
 
 enum {

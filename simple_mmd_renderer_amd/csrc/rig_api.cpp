@@ -250,6 +250,8 @@ mmdx_status mmdx_skeleton_get_info(mmdx_skeleton_t s, mmdx_skeleton_info *info) 
     info->n_append_bones = s->plan.n_append;
     info->n_bone_morph_entries = uint32_t(s->plan.apps.size());
     info->n_solve_rounds = uint32_t(s->plan.rounds.size());
+    info->n_ik_rounds_16_lanes = 0;
+    for (uint8_t c : s->plan.round_coop) info->n_ik_rounds_16_lanes += (c && !s->plan.nested_ik) ? 1u : 0u;
     return MMDX_OK;
 }
 

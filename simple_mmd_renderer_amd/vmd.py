@@ -216,7 +216,8 @@ class SkeletonInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_bones", C.c_uint32), ("n_pre_physics", C.c_uint32),
                 ("n_post_physics", C.c_uint32), ("max_chain", C.c_uint32), ("solver", C.c_uint32),
                 ("n_ik_bones", C.c_uint32), ("n_ik_links", C.c_uint32), ("n_append_bones", C.c_uint32),
-                ("n_bone_morph_entries", C.c_uint32), ("n_solve_rounds", C.c_uint32)]
+                ("n_bone_morph_entries", C.c_uint32), ("n_solve_rounds", C.c_uint32),
+                ("n_ik_rounds_16_lanes", C.c_uint32)]
 
 
 SOLVER_PARALLEL_FK, SOLVER_SERIAL = 0, 1

@@ -139,6 +139,48 @@ def test_host_rates_unchanged_skip_the_launch_and_every_other_writer_voids_the_r
             b.free()
 
 
+def test_models_past_the_fused_flatten_limit_and_f16_models(oracle):
+    """More than 8 192 slots: the morph pass runs behind a separate flatten launch and keeps no record of its rates (every call
+    walks, results exact); an f16-position model takes the recorded path like an f32 one."""
+    ni = 12
+    big = synth.make_model(900, 12, 8300, 2, seed=77)                    # 8 300 vertex morphs of 2 entries each
+    pals = synth.make_palettes(big, np.arange(ni))
+    r = synth.morph_weights(big.nm, 9)[0]
+    skin = oracle.normalize(big)
+    with DeformModel(big) as dm:
+        for k in range(3):
+            pos, nrm = dm.deform_batched(r, pals, shared_weights=True)
+            want = expect(oracle, big, r, pals, skin, (0, ni - 1))
+            for i, (ep, en) in want.items():
+                gu.assert_bits_equal(pos[i], ep, f"call {k} inst {i} pos")
+                gu.assert_bits_equal(nrm[i], en, f"call {k} inst {i} nrm")
+        walks, dskips, hskips = dm.morph_pass_stats()
+        assert dskips == 0 and hskips == 2          # the HOST comparison still works (it needs no device record); no device skip
+    m = synth.make_model(3000, 30, 10, 200, seed=78)
+    q = m.copy()
+    q.positions = m.positions.astype(np.float16).astype(np.float32)
+    q.morph_value = m.morph_value.astype(np.float16).astype(np.float32)
+    pals = synth.make_palettes(m, np.arange(ni))
+    r = synth.morph_weights(m.nm, 21)[0]
+    skin = oracle.normalize(q)
+    with DeformModel(m, f16_positions=True) as dm:
+        d_w, d_pal = DeviceBuffer.from_numpy(r), DeviceBuffer.from_numpy(pals)
+        sa, sb = dm.out_sizes(api.OUT_SOA_POS16, ni)
+        d_a, d_b = DeviceBuffer(sa), DeviceBuffer(sb)
+        for k in range(3):
+            d_a.memset(0xFF); d_b.memset(0xFF)
+            dm.deform_batched_raw(ni, d_w.ptr, d_pal.ptr, d_a.ptr, d_b.ptr, api.OUT_SOA_POS16, DEV)
+            dm.sync()
+        assert dm.morph_pass_stats() == (1, 2, 0)
+        want = expect(oracle, q, r, pals, skin, (0, ni - 1))
+        for i, (ep, en) in want.items():
+            got16 = d_a.download((m.nv, 3), np.float16, offset=i * m.nv * 6)
+            assert np.array_equal(got16.view(np.uint16), ep.astype(np.float16).view(np.uint16)), f"f16 inst {i} pos"
+            gu.assert_bits_equal(d_b.download((m.nv, 3), np.float32, offset=i * m.nv * 12), en, f"f16 inst {i} nrm")
+        for b in (d_w, d_pal, d_a, d_b):
+            b.free()
+
+
 def test_autoskip_can_be_switched_off_for_ab_runs(oracle, crowd):
     m, ni, pals = crowd
     r0 = synth.morph_weights(m.nm, 30)[0]

@@ -202,6 +202,35 @@ def test_solve_round_schedule_host_side(monkeypatch):
     assert vmd.Skeleton(rest, parent, level, flags, ap, ar, ik).info["n_solve_rounds"] == 300
 
 
+def test_ik_rounds_that_run_with_sixteen_lanes_per_solve_host_side():
+    """Which rounds of the schedule go to the 16-lanes-per-solve kernel (rig.cpp round_coop, mmdx_skeleton_info): rounds made of
+    CCD-IK solves on plain chains -- the bench rig's eight chains share ONE such round; a chain longer than the kernel's six links
+    is solved by the ordered kernel; a rig with nested IK keeps one lane per solve throughout; FK / append-only rigs have none."""
+    rig = synth.make_ik_rig(300, 3003, n_ik=8, n_append=12, post_physics=0.0, levels=1)         # tools/rig_bench.py's IK rig
+    info = vmd.Skeleton(*rig).info
+    assert info["n_ik_bones"] == 8 and 1 <= info["n_ik_rounds_16_lanes"] <= 8 and info["n_ik_rounds_16_lanes"] < info["n_solve_rounds"]
+    assert vmd.Skeleton(rig[0], rig[1]).info["n_ik_rounds_16_lanes"] == 0
+    no_ik = (np.asarray(rig[3]) & ~np.uint16(0x20)).astype(np.uint16)
+    assert vmd.Skeleton(rig[0], rig[1], rig[2], no_ik, rig[4], rig[5]).info["n_ik_rounds_16_lanes"] == 0
+    nested = synth.make_nested_ik_rig(60, 11)
+    assert vmd.Skeleton(*nested).info["n_ik_rounds_16_lanes"] == 0
+    nb = 40                                                   # one 7-link chain on a line: past kMaxFastLinks
+    rest = np.stack([np.zeros(nb), np.arange(nb) * 0.1, np.zeros(nb)], 1).astype(np.float32)
+    parent = np.arange(-1, nb - 1).astype(np.int32)
+    parent[nb - 1] = 0
+    flags = np.zeros(nb, np.uint16)
+    flags[nb - 1] = 0x20
+    for n_links, want in ((6, 1), (7, 0)):
+        links = list(range(nb - 3, nb - 3 - n_links, -1))
+        ik = dict(target=np.full(nb, -1, np.int32), loop=np.zeros(nb, np.int32), angle=np.zeros(nb, np.float32),
+                  link_off=np.zeros(nb + 1, np.uint32), link_bone=np.asarray(links, np.int32),
+                  link_limited=np.zeros(n_links, np.uint8), link_lo=np.zeros((n_links, 3), np.float32),
+                  link_hi=np.zeros((n_links, 3), np.float32))
+        ik["target"][nb - 1], ik["loop"][nb - 1], ik["angle"][nb - 1] = nb - 2, 12, 1.0
+        ik["link_off"][nb:] = n_links
+        assert vmd.Skeleton(rest, parent, None, flags, None, None, ik).info["n_ik_rounds_16_lanes"] == want, n_links
+
+
 IK_CASES = [(30, 0, 2, 2), (44, 1, 3, 4), (80, 2, 5, 6), (150, 3, 6, 10), (61, 4, 4, 0), (52, 5, 0, 8)]
 
 
