@@ -40,6 +40,14 @@
 #define MMDX_K(name) name
 #endif
 
+// Timing-diagnostic build knobs (PK_SKIP_WALK, PK_SKIP_SKIN, FUSED4_SKIP_WALK: a kernel without one of its halves -- WRONG results by
+// design; PK_STAMPS: in-kernel cycle stamps): only together with MMDX_DIAGNOSTIC_BUILD, and never the product -- the build's flags
+// are part of the source stamp (build.py source_sha), so bench.py / smoke() refuse such a library unless it is loaded explicitly
+// through MMDX_LIB by a tool.
+#if (defined(PK_SKIP_WALK) || defined(PK_SKIP_SKIN) || defined(FUSED4_SKIP_WALK) || defined(PK_STAMPS)) && !defined(MMDX_DIAGNOSTIC_BUILD)
+#error "PK_SKIP_* / FUSED4_SKIP_WALK / PK_STAMPS are timing diagnostics (wrong results): add MMDX_DIAGNOSTIC_BUILD to MMDX_BUILD_DEFS"
+#endif
+
 namespace mmdx {
 namespace {
 
@@ -1317,8 +1325,6 @@ __global__ __launch_bounds__(kPkThreads, PK_WAVES) void pack_kernel(const Deform
             instance(j, std::false_type{});
         }
         if (first_instance(g0) + kPkPack - 1 < p.ni) instance(kPkPack - 1, std::true_type{});
-#endif
-#ifdef PK_SKIP_SKIN          // timing diagnostic only (wrong results): the walk alone -- instances are skipped by the macro below
 #endif
         if (more) {
             // every wave has left this pack's walk (it passed the instances' barriers): the weights can be replaced.  The barrier

@@ -260,6 +260,9 @@ using ChainState = StateT<__attribute__((address_space(3))) float *, true>;  // 
 // float(sqrt(double(x))) is the correctly rounded f32 square root (rounding twice is innocuous for sqrt when the
 // wide format has >= 2 x 24 + 2 bits), which is what sqrtf compiles to; sincos shares its argument reduction and
 // polynomials with sin and cos.  Both substitutions checked over all 2^32 floats: tools/archive/probes/libm_probe.hip.
+#if defined(IK_FAKE_LIBM) && !defined(MMDX_DIAGNOSTIC_BUILD)
+#error "IK_FAKE_LIBM is a timing diagnostic (wrong results): add MMDX_DIAGNOSTIC_BUILD to MMDX_BUILD_DEFS"
+#endif
 #ifdef IK_FAKE_LIBM     // timing diagnostic only (wrong results): what the solver costs without its double-precision libm calls
 __device__ __forceinline__ float d_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ void d_sincos(float x, float *s, float *c) { *s = x - x * x * x * 0.16f; *c = 1.0f - x * x * 0.5f; }
