@@ -787,8 +787,10 @@ __device__ __forceinline__ void stagger_start(const DeformParams &p) {
 #define MMDX_WALK_ROLLING 1
 #endif
 #ifndef MMDX_WALK_PREFETCH
-#define MMDX_WALK_PREFETCH 0       // the next pack's row head requested in front of a pack's last stores: 147 VGPRs instead of 118 (f32), i.e.
-#endif                             // one workgroup per CU instead of two, or 48 spills under a 128-register bound -- off; pack_kernel does it for free
+#define MMDX_WALK_PREFETCH 0       // the next pack's row head requested in front of a pack's last stores: 144 VGPRs instead of 118 (f32), i.e.
+#endif                             // one workgroup per CU instead of two, or 44 spills under a 128-register bound whose reloads sit between the
+                                   // instances' stores -- off.  (It could hide the first round trip only: every later request of the walk still
+                                   // queues behind those stores.  pack_kernel has the registers for it and loses all the same.)
 template <bool F16, bool ROLLING, typename Body>
 __device__ __forceinline__ void fused4_walk(const void *entries, uint32_t rb, uint32_t rlen, Body body) {
     if constexpr (ROLLING && MMDX_WALK_ROLLING != 0) walk_rolling<F16>(entries, rb, __builtin_amdgcn_readfirstlane(rlen), body);
@@ -999,7 +1001,11 @@ __global__ __launch_bounds__(THREADS) void deform_kernel(const DeformParams p) {
                 if (g0 + kPack - 1 < gcount) one(kPack - 1, NoHook{});
                 break;
             }
-            if constexpr (kHead) one(kPack - 1, [&]() { walk_head<F16>(p.entries, sl[0].rb, hlen, head); });
+            if constexpr (kHead) one(kPack - 1, [&]() {
+                uint32_t rb = sl[0].rb;
+                asm volatile("" : "+v"(rb));          // (pins the requests behind the barrier: hoisted into the skinning they cost it 16 registers)
+                walk_head<F16>(p.entries, rb, hlen, head);
+            });
             else one(kPack - 1, NoHook{});
             {
                 // every wave has left this pack's walk (it passed the barriers of the pack's instances): the weights can
