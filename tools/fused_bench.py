@@ -65,6 +65,13 @@ def main():
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
     if "c2" in which or "c3p" in which or "c2x1" in which:
         m = synth.make_config("config2_50k")
+        # FB_WINDOW=12: the same model with bone ids drawn from a window of 12 (<= 16 bones per tile: the palette gathers cannot
+        # conflict); FB_PRESORT=1: vertices pre-sorted the way the plan sorts them (the scatter into the LDS image is the identity)
+        if os.environ.get("FB_WINDOW"):
+            c = synth.CONFIGS["config2_50k"]
+            m = synth.make_model(c["nv"], c["nb"], c["nm"], c["k"], c["seed"], window=int(os.environ["FB_WINDOW"]))
+        if os.environ.get("FB_PRESORT") == "1":
+            m = synth.presort_by_class(m)
         if "c2" in which:
             run("c2x64", m, 64, np.arange(64), api.OUT_SOA, iters)
         if "c2x1" in which:
