@@ -21,6 +21,12 @@ rig = synth.make_ik_rig(m.nb, 3003, n_ik=8, n_append=12, post_physics=0.0, level
 rigs = {"fk": vmdmod.Skeleton(m.bone_pos, np.asarray(m.bone_parent, np.int32)),
         "append": vmdmod.Skeleton(rig[0], rig[1], rig[2], (np.asarray(rig[3]) & ~np.uint16(0x20)).astype(np.uint16), rig[4], rig[5]),
         "ik": vmdmod.Skeleton(*rig)}
+# the same IK rig with its iteration limits capped at 40, the value the leg-IK bones of MMD models usually carry (the rig above
+# draws 300 -> 256 for some chains: one chain of 256 x 3 link steps is what the "ik" row waits for)
+rig40 = list(rig)
+_l = rig[6]["loop"].astype(np.int64)
+rig40[6] = dict(rig[6], loop=np.where((_l < 0) | (_l > 40), 40, _l).astype(rig[6]["loop"].dtype))   # (-1 reads as "no limit")
+rigs["ik40"] = vmdmod.Skeleton(*rig40)
 # RIG_NI=1024,4096,16384: the same rigs at larger crowds (task 7: 1024 instances are 256 waves, one per CU on a
 # quarter of the SIMDs -- what does the solver do when the chip is filled?); RIG_ONLY=ik restricts the rigs
 for ni in [int(x) for x in os.environ.get("RIG_NI", "1024").split(",")]:
@@ -29,7 +35,7 @@ for ni in [int(x) for x in os.environ.get("RIG_NI", "1024").split(",")]:
     for name, sk in rigs.items():
         if os.environ.get("RIG_ONLY") and name not in os.environ["RIG_ONLY"].split(","):
             continue
-        iters = max(2, (10 if name == "ik" else 30) * 1024 // ni)
+        iters = max(2, (10 if name.startswith("ik") else 30) * 1024 // ni)
         ms = bench.time_calls(dm, lambda: (bm.eval_device(ni, d_fr.ptr, d_pose.ptr, dm), sk.solve_device(ni, d_pose.ptr, d_pal.ptr, dm)),
                               iters)
         ms1 = bench.time_calls(dm, lambda: sk.solve_motion_device(bm, ni, d_fr.ptr, d_pal.ptr, dm), iters)
